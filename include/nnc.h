@@ -1,0 +1,197 @@
+/*
+ * nnc.h -- C ABI of libnnc_hip.so: the MI355X (gfx950) implementation of the per-layer
+ * Deep-Compression hot path of angelocatalani/neural-network-compression:
+ *
+ *     magnitude-threshold pruning  ->  Lloyd k-means weight quantisation  ->
+ *     centroid-index re-encode (+ index histogram / Huffman code lengths)
+ *
+ * The reference has no FFI of its own (it is ~870 lines of Python on NumPy /
+ * scikit-learn); the boundary it offers is three module-level functions and the Trainer
+ * methods that call them.  Each entry point below names the reference lines it replaces
+ * (paths relative to the reference repo root); INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative NNC_E* code on failure;
+ *     nnc_last_error() gives the message of the calling thread's last failure;
+ *   - pointers named *_dev / x / mask / labels are DEVICE pointers (hipMalloc'ed or
+ *     torch.Tensor.data_ptr()); nothing is allocated behind the caller's back: scratch is
+ *     a caller-owned device workspace sized by the *_workspace_bytes() functions;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is
+ *     enqueued asynchronously on it, no entry point synchronises unless it says so;
+ *   - float32 arithmetic that decides a mask bit or a centroid index reproduces the
+ *     reference's NumPy / scikit-learn float32 arithmetic exactly (no FMA contraction).
+ *
+ * Fixed-point sums ("mode B").  Per-cluster sums are exact 64-bit integer sums of
+ *     fix(v) = sign(v) * floor(|v| * 2^S + 1/2)          (v = float32 centred weight)
+ * so that they do not depend on summation order, block count or GPU count; the new
+ * centre is (float) ldexp((double)sum / (double)count, -S).  S = 62 - L - P with
+ * L = ceil(log2(n_total)) and 2^P > max|v| (nnc_fix_shift()).
+ */
+#ifndef NNC_H
+#define NNC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NNC_VERSION 100
+
+#define NNC_OK 0
+#define NNC_EINVAL (-1)   /* bad argument (null pointer, size, k out of range ...) */
+#define NNC_ENOSPACE (-2) /* workspace too small */
+#define NNC_EHIP (-3)     /* a HIP runtime call failed; see nnc_last_error() */
+#define NNC_ENODEV (-4)   /* no gfx950 device / wrong architecture */
+
+#define NNC_KMAX 1040     /* largest supported number of centroids (2^10 + 1 for density init) */
+#define NNC_CHUNK 8192    /* NumPy's reduction buffer: float32 sums are folded per 8192-element chunk */
+
+int nnc_version(void);
+const char *nnc_last_error(void);
+/* Fills name (e.g. "gfx950") and the CU count of the current device. */
+int nnc_device_info(char *arch_out, size_t arch_len, int *cu_count_out);
+
+/* ------------------------------------------------------------------------------------
+ * NumPy-exact float32 reductions (np.sum / np.mean / np.var / np.std on float32):
+ * replaces the np.std call in prune_weigth (neural_network_compression/common/utility.py:159)
+ * and the X.mean / np.var calls scikit-learn's KMeans.fit makes on the weights
+ * (utility.py:237-238 -> sklearn/cluster/_kmeans.py:279-287,1479-1484).
+ * ---------------------------------------------------------------------------------- */
+
+/* chunk_out[c] = NumPy pairwise sum of x[c*8192 : (c+1)*8192]           (sqdev == 0)
+ *              = same tree over (x[i] - *mean_dev)^2 in float32          (sqdev != 0)
+ * nchunks = ceil(n / 8192).  Shards of a longer vector must start on a multiple of 8192. */
+int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const float *mean_dev, float *chunk_out,
+                       void *stream);
+
+#define NNC_FOLD_SUM 0  /* out = fold                                   */
+#define NNC_FOLD_MEAN 1 /* out = (float)((double)fold / count)           */
+#define NNC_FOLD_STD 2  /* out = sqrtf((float)((double)fold / count))    */
+/* Left-to-right float32 fold of nchunks chunk sums (NumPy's order), then `op`.
+ * out_dev[0] = result; if scale_dev != NULL additionally out_dev[1] = result * *scale_dev. */
+int nnc_fold_f32(const float *chunks, int64_t nchunks, int64_t count, int op, const float *scale_dev,
+                 float *out_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pruning: utility.prune_weigth (common/utility.py:134-163), and the re-application of
+ * stored masks, Trainer._reset_pruned_parameters (common/trainer.py:195-206).
+ * ---------------------------------------------------------------------------------- */
+
+size_t nnc_prune_workspace_bytes(int64_t n);
+
+/* mask[i] = |x[i]| < thr ; x[i] = 0 where mask ; thr = std(x) * q if std_smooth else q.
+ * stats_dev (device float[2]) receives {sigma, thr}; nzeroed_dev (device int64) the number of
+ * mask bits set.  q is the float32 the NumPy comparison would use (host resolves NEP 50). */
+int nnc_prune_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev,
+                  int64_t *nzeroed_dev, void *ws, size_t ws_bytes, void *stream);
+
+/* Same elementwise pass with the threshold already on the device (sharded pruning: the
+ * ranks all-gather their chunk sums, fold, and each thresholds its own shard). */
+int nnc_threshold_mask_f32(float *x, int64_t n, const float *thr_dev, uint8_t *mask, int64_t *nzeroed_dev,
+                           void *stream);
+
+/* x[i] = 0 where mask[i]  (trainer.py:203-205). */
+int nnc_apply_mask_f32(float *x, const uint8_t *mask, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight distribution: the data passes of utility.get_weight_distribution
+ * (common/utility.py:362-372) and of the linear init (utility.py:207-208).
+ * ---------------------------------------------------------------------------------- */
+
+size_t nnc_minmax_workspace_bytes(int64_t n);
+/* out_dev[0] = min, out_dev[1] = max over the elements (over the non-zero ones if
+ * skip_zeros: Trainer.quantize strips exact zeros first, trainer.py:55-59);
+ * count_dev = number of elements considered. */
+int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev, void *ws,
+                   size_t ws_bytes, void *stream);
+
+/* counts_dev[b] += #{ i : steps[b] <= x[i] < steps[b+1] }, b = 0..30 (caller zeroes counts_dev). */
+int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps32_dev, int64_t *counts_dev,
+                   void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Lloyd k-means on the flattened weights: KMeans(n_clusters=K, init=space, n_init=1,
+ * algorithm="full").fit(w.reshape(-1,1)) and the gather cluster_centers_[labels_]
+ * (common/utility.py:237-239; scikit-learn's _kmeans.py:624-752, _k_means_lloyd.pyx:23-218,
+ * _k_means_common.pyx:167-311).
+ *
+ * One iteration = nnc_kmeans_accumulate (E-step + per-cluster fixed-point sums over this
+ * rank's shard) -> [all-reduce of nnc_kmeans_partials() across ranks] -> nnc_kmeans_finalize
+ * (average, centre shift, tolerance test, search table for the next E-step).
+ * nnc_kmeans_iterate enqueues `iters` such iterations back to back for the single-GPU case.
+ * All state lives in the caller's workspace; once the state says done (or paused) further
+ * iterations are no-ops, so the host may enqueue batches and look at the status afterwards.
+ * The entry points that size a launch take the same (host) nnc_kmeans_params the workspace
+ * was initialised with.
+ * ---------------------------------------------------------------------------------- */
+
+typedef struct nnc_kmeans_params {
+    int64_t n;         /* length of this rank's shard */
+    int64_t n_total;   /* length of the whole vector (all ranks) */
+    int32_t k;         /* number of centroids, 1..NNC_KMAX */
+    int32_t max_iter;  /* scikit-learn default 300 */
+    int32_t fix_shift; /* S of the fixed-point sums, from nnc_fix_shift() */
+    int32_t grid_log2; /* log2 of the number of cells of the search grid; 0 = library default */
+    int32_t replicas_log2; /* log2 of LDS accumulator replicas; -1 = library default */
+    int32_t reserved;
+    float x_mean;      /* NumPy float32 mean of the whole vector */
+    float tol;         /* float32(np.var(x)) * float32(1e-4) */
+    float lo, hi;      /* min and max of the centred data x - x_mean (float32) */
+} nnc_kmeans_params;
+
+typedef struct nnc_kmeans_status {
+    int32_t iter;      /* completed Lloyd iterations (scikit-learn's n_iter_ when done) */
+    int32_t done;      /* 1: centre shift <= tol, 2: max_iter reached, 3: set by host (strict) */
+    int32_t paused;    /* 1: an empty cluster was found; host must relocate, then resume */
+    int32_t n_empty;   /* number of empty clusters when paused */
+    float shift_tot;   /* last sum of squared centre shifts (float32, NumPy order) */
+    float tol;
+    int32_t k;
+    int32_t reserved;
+} nnc_kmeans_status;
+
+int32_t nnc_fix_shift(float absmax, int64_t n_total);
+size_t nnc_kmeans_workspace_bytes(int32_t k);
+
+/* centers_init_dev: k float32, un-centred (the reference's `space`).  Resets the state. */
+int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
+                    void *stream);
+int nnc_kmeans_accumulate(const float *x, void *ws, const nnc_kmeans_params *p, void *stream);
+/* device int64[2*k]: sums (fixed point) then counts, indexed by centroid; valid after
+ * nnc_kmeans_accumulate; the caller may all-reduce (SUM) or edit it before finalize. */
+int64_t *nnc_kmeans_partials(void *ws);
+/* resume = 0: normal; if a cluster is empty, set paused and change nothing else.
+ * resume = 1: clear paused and finalize with the (host-edited) partials as they are. */
+int nnc_kmeans_finalize(void *ws, int resume, void *stream);
+int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *p, int32_t iters, void *stream);
+/* Asynchronous copy of the status block to host_out (pinned or pageable host memory). */
+int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, void *stream);
+int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream);
+/* which: 0 = current centres (used by the next E-step), 1 = centres of the previous E-step.
+ * centred != 0: as stored (x_mean subtracted); else un-centred (+ x_mean, float32 add). */
+int nnc_kmeans_get_centers(void *ws, int which, int centred, float *out_dev, void *stream);
+
+/* E-step only, against the CURRENT centres (which = 0) or the PREVIOUS ones (which = 1):
+ * any of the outputs may be NULL.
+ *   labels_out : centroid index per element, uint8 if label_bytes == 1 (k <= 256) else uint16
+ *   quant_out  : cluster_centers_[labels_] (un-centred float32 centre values), utility.py:239
+ *   dist_out   : (x~ - c~[label])^2 in float32, the distances _relocate_empty_clusters needs */
+int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int which, void *labels_out,
+                      int label_bytes, float *quant_out, float *dist_out, void *stream);
+
+/* counts_dev[j] += #{ i : labels[i] == j }  (caller zeroes counts_dev; int64[k]). */
+int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream);
+
+/* Huffman code length per centroid index from the index histogram (HOST function, host
+ * pointers).  The reference names Huffman coding (README.md:9) but never implements it; the
+ * definition is in DESIGN.md.  lengths_out[k]; hist_out[65] (hist_out[l] = symbols of length l). */
+int nnc_huffman_lengths(const int64_t *counts, int32_t k, uint8_t *lengths_out, int64_t *hist_out,
+                        int64_t *total_bits_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NNC_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of include/nnc.h (csrc/libnnc_hip.so).
+
+There is NO CPU fallback: if the HIP library is missing or fails to load, every product
+entry point raises ``NativeLibraryError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from . import build as _build
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_i32 = ctypes.c_int32
+c_i64 = ctypes.c_int64
+c_f32 = ctypes.c_float
+c_size = ctypes.c_size_t
+
+NNC_OK = 0
+NNC_KMAX = 1040
+NNC_CHUNK = 8192
+FOLD_SUM, FOLD_MEAN, FOLD_STD = 0, 1, 2
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class NncError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"nnc error {code}: {message}")
+        self.code = code
+
+
+class KMeansParams(ctypes.Structure):
+    _fields_ = [
+        ("n", c_i64), ("n_total", c_i64), ("k", c_i32), ("max_iter", c_i32), ("fix_shift", c_i32),
+        ("grid_log2", c_i32), ("replicas_log2", c_i32), ("reserved", c_i32),
+        ("x_mean", c_f32), ("tol", c_f32), ("lo", c_f32), ("hi", c_f32),
+    ]
+
+
+class KMeansStatus(ctypes.Structure):
+    _fields_ = [
+        ("iter", c_i32), ("done", c_i32), ("paused", c_i32), ("n_empty", c_i32),
+        ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("reserved", c_i32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/nnc.h declares
+SIGNATURES = {
+    "nnc_version": (c_int, []),
+    "nnc_last_error": (ctypes.c_char_p, []),
+    "nnc_device_info": (c_int, [ctypes.c_char_p, c_size, ctypes.POINTER(c_int)]),
+    "nnc_chunk_sums_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "nnc_fold_f32": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "nnc_prune_workspace_bytes": (c_size, [c_i64]),
+    "nnc_prune_f32": (c_int, [c_void_p, c_i64, c_f32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_threshold_mask_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nnc_apply_mask_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
+    "nnc_minmax_workspace_bytes": (c_size, [c_i64]),
+    "nnc_minmax_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_hist31_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "nnc_fix_shift": (c_i32, [c_f32, c_i64]),
+    "nnc_kmeans_workspace_bytes": (c_size, [c_i32]),
+    "nnc_kmeans_init": (c_int, [c_void_p, c_size, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
+    "nnc_kmeans_accumulate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_void_p]),
+    "nnc_kmeans_partials": (c_void_p, [c_void_p]),
+    "nnc_kmeans_finalize": (c_int, [c_void_p, c_int, c_void_p]),
+    "nnc_kmeans_iterate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p]),
+    "nnc_kmeans_status_async": (c_int, [c_void_p, ctypes.POINTER(KMeansStatus), c_void_p]),
+    "nnc_kmeans_set_done": (c_int, [c_void_p, c_i32, c_void_p]),
+    "nnc_kmeans_get_centers": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "nnc_kmeans_assign": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
+    "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+}
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load():
+    """Load libnnc_hip.so (must have been built: ``__graft_entry__.build()`` or
+    ``python -m neural_network_compression_amd.build``).  Raises NativeLibraryError."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `python -m neural_network_compression_amd.build`); there is no CPU fallback")
+    try:
+        L = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise NativeLibraryError(f"cannot load {path}: {e}; there is no CPU fallback") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{path} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != NNC_OK:
+        raise NncError(rc, load().nnc_last_error().decode("utf-8", "replace"))

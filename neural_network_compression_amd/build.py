@@ -1,0 +1,52 @@
+"""Builds csrc/libnnc_hip.so (gfx950) in-tree with hipcc.
+
+``python -m neural_network_compression_amd.build`` or ``build_native()``.  hipcc
+cross-compiles without a GPU, so this also runs in the CPU-only build container; the
+resulting .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
+LIB = os.path.join(CSRC, "libnnc_hip.so")
+SOURCES = [os.path.join(CSRC, "nnc_hip.hip")]
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = SOURCES + [os.path.join(INCLUDE, "nnc.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_native(force: bool = False, verbose: bool = False) -> str:
+    if not force and not is_stale():
+        return LIB
+    cmd = [
+        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17",
+        "-ffp-contract=off",  # the reference arithmetic is unfused float32; never contract
+        "-fPIC", "-shared", "-I", INCLUDE, "-o", LIB,
+    ] + SOURCES
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+    if verbose:
+        print(proc.stdout + proc.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_native(force=True, verbose=True))

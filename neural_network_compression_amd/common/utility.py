@@ -1,0 +1,185 @@
+"""Drop-in counterparts of the reference's compression primitives, running on MI355X.
+
+Same names, arguments, return values and error behaviour as
+``neural_network_compression/common/utility.py`` of the reference:
+
+    prune_weigth(original_weigth, threshold=0.25, std_smooth=True)          utility.py:134-163
+    get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None)     utility.py:172-240
+    get_weight_distribution(weight_matrix)                                   utility.py:334-392
+
+Arguments may be NumPy arrays (the reference's calling convention: the data crosses PCIe,
+results come back as NumPy arrays, ``prune_weigth`` still mutates its argument) or float32
+CUDA tensors already resident in HBM (no host copy of the weights at all; results are CUDA
+tensors).  The arithmetic runs in the HIP kernels of csrc/nnc_hip.hip through the C ABI of
+include/nnc.h; the few K-sized host steps (linspace, the density pick, the forgy draw) use
+the same NumPy calls the reference makes so that their dtype/rounding behaviour is inherited.
+There is no CPU fallback: without the HIP library these functions raise.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import kmeans as _kmeans
+from .. import ops
+
+_DEVICE = None
+
+
+def default_device() -> torch.device:
+    global _DEVICE
+    if _DEVICE is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("neural_network_compression_amd needs an MI355X (no GPU visible, no CPU fallback)")
+        _DEVICE = torch.device("cuda", torch.cuda.current_device())
+    return _DEVICE
+
+
+def _to_device(a):
+    """-> (flat float32 CUDA tensor, was_numpy).  NumPy input is copied host->HBM."""
+    if isinstance(a, torch.Tensor):
+        if not a.is_cuda:
+            raise TypeError("torch tensors must live on the GPU; pass a NumPy array for host data")
+        if a.dtype != torch.float32:
+            raise TypeError("weights must be float32")
+        return a.contiguous().reshape(-1), False
+    arr = np.asarray(a)
+    if arr.dtype != np.float32:
+        raise TypeError(f"weights must be float32 (the reference feeds Keras float32 weights), got {arr.dtype}")
+    t = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1)).to(default_device())
+    return t, True
+
+
+def _threshold_f32(sigma, threshold, std_smooth):
+    """float32 t with (|w| < t) == (|w| < np.std(w)*threshold  or  |w| < threshold) for float32 w
+    under NumPy-2 promotion: python scalars are weak (float32 arithmetic), a float64 NumPy
+    scalar forces a float64 comparison, which equals comparing against t rounded UP to float32."""
+    thr = (np.float32(sigma) * threshold) if std_smooth else threshold
+    if isinstance(thr, np.float64):
+        t32 = np.float32(thr)
+        if np.float64(t32) < thr:
+            t32 = np.nextafter(t32, np.float32(np.inf), dtype=np.float32)
+        return np.float32(t32)
+    return np.float32(thr)
+
+
+# ------------------------------------------------------------------------------------------
+def prune_weigth(original_weigth, threshold=0.25, std_smooth=True):
+    """Zero the weights whose magnitude is below ``threshold`` (times the tensor's standard
+    deviation if ``std_smooth``) IN PLACE and return the boolean mask of the zeroed entries.
+    Reference: utility.py:134-163 (np.std, np.abs(w) < thr, w[mask] = 0)."""
+    x, was_numpy = _to_device(original_weigth)
+    shape = tuple(original_weigth.shape)
+    simple = isinstance(threshold, (int, float, np.float32)) and not isinstance(threshold, (np.float64, bool))
+    if x.numel() == 0:
+        mask = torch.zeros(0, dtype=torch.uint8, device=x.device)
+    elif simple:
+        mask, _, _ = ops.prune_(x, np.float32(threshold), bool(std_smooth))
+    else:
+        sigma = ops.moments(x)[2].cpu().numpy()[0] if std_smooth else np.float32(0)
+        thr = torch.tensor([_threshold_f32(sigma, threshold, std_smooth)], dtype=torch.float32, device=x.device)
+        mask, _ = ops.threshold_mask_(x, thr)
+    if was_numpy:
+        np.copyto(original_weigth, x.cpu().numpy().reshape(shape))
+        return mask.cpu().numpy().view(np.bool_).reshape(shape)
+    if x.data_ptr() != original_weigth.data_ptr():
+        original_weigth.copy_(x.view(shape))
+    return mask.view(torch.bool).view(shape)
+
+
+# ------------------------------------------------------------------------------------------
+def _cdf_from_counts(steps: np.ndarray, counts: np.ndarray):
+    """utility.py:374-392 on the 32 steps and the 31 integer bin counts (host, 31 values)."""
+    from scipy.interpolate import interp1d
+
+    x = steps[:-1]
+    tot_counter = np.array([int(c) for c in counts]) / (np.sum([int(c) for c in counts]))
+    cdf = []
+    for i in range(len(tot_counter)):
+        cdf.append(tot_counter[i] if i == 0 else tot_counter[i] + cdf[i - 1])
+    cdf = np.array(cdf)
+    cdf = cdf / cdf[-1]
+    xnew = np.linspace(min(x), max(x), 300)
+    spl = interp1d(x, cdf, "linear")
+    return xnew, spl(xnew)
+
+
+def _weight_distribution_device(x: torch.Tensor, skip_zeros: bool):
+    mm, cnt = ops.minmax(x, skip_zeros=skip_zeros)
+    host = mm.cpu().numpy()
+    if skip_zeros and int(cnt.item()) == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    steps = np.linspace(np.float32(host[0]), np.float32(host[1]), num=32)  # float32 under NumPy 2
+    steps_d = torch.from_numpy(np.ascontiguousarray(steps, dtype=np.float32)).to(x.device)
+    counts = ops.hist31(x, steps_d, skip_zeros=skip_zeros).cpu().numpy()
+    return _cdf_from_counts(steps, counts)
+
+
+def get_weight_distribution(weight_matrix, skip_zeros: bool = False):
+    """(xnew[300], cdf[300]): 31-bin histogram over linspace(min, max, 32) -> cumulative ->
+    normalised -> linear interpolation at 300 points.  Reference: utility.py:334-392.
+
+    ``skip_zeros=True`` (extension) ignores exact zeros on the device instead of having the
+    caller strip them first (Trainer.quantize does ``numpy.delete`` of the zeros,
+    common/trainer.py:55-59); the result is identical to passing the stripped vector."""
+    if not isinstance(weight_matrix, torch.Tensor) and np.asarray(weight_matrix).size == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    x, _ = _to_device(weight_matrix)
+    return _weight_distribution_device(x, skip_zeros)
+
+
+# ------------------------------------------------------------------------------------------
+def _init_space(x: torch.Tensor, n: int, bits: int, mode: str, cdfs):
+    """The reference's three explicit centroid initialisations (utility.py:206-226)."""
+    if mode == "linear":
+        mm, _ = ops.minmax(x)
+        host = mm.cpu().numpy()
+        return np.linspace(np.float32(host[0]), np.float32(host[1]), num=2 ** bits)
+    if mode == "density" and cdfs is not None:
+        tmp = np.linspace(0, 1, num=(2 ** bits) + 1)
+        xval, yval = cdfs[0], cdfs[1]
+        space = []
+        for i in range(len(tmp)):
+            minval = min(yval, key=lambda v: abs(v - tmp[i]))
+            idx_val = np.argmax(yval == minval)
+            space.append(xval[idx_val])
+        return np.array(space)
+    if mode == "forgy":
+        # np.random.choice(flat, size=K) draws K indices with the legacy global RNG
+        # (randint(0, N, K)) and gathers; draw the same indices, gather on the device
+        idx = np.random.randint(0, n, size=2 ** bits)
+        return x[torch.from_numpy(idx).to(x.device)].cpu().numpy()
+    raise Exception(" error mode not found")
+
+
+def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=None):
+    """Replace every weight by the centroid of its k-means cluster (2**bits centroids;
+    2**bits + 1 for ``density``).  Returns ``(quantized weights, fitted model)`` where the
+    model exposes ``cluster_centers_``, ``labels_`` and ``n_iter_`` like the scikit-learn
+    object the reference returns.  Reference: utility.py:172-240.
+
+    Same corner cases: fewer than ``2**bits + 1`` weights -> prints "not enough bits" and
+    returns ``(layer_weight, None)``; unknown mode, or ``density`` without ``cdfs`` ->
+    ``Exception(" error mode not found")``.  ``kmeans++`` (a 4th mode of the reference that
+    the hot path does not cover) raises NotImplementedError.
+
+    ``group``: a torch.distributed process group when ``layer_weight`` is this rank's
+    contiguous shard of a longer vector (shards start on multiples of 8192 elements)."""
+    n = int(np.prod(layer_weight.shape))
+    if group is None and n < (2 ** bits) + 1:
+        print("not enough bits:", n, " vs ", 2 ** bits)
+        return layer_weight, None
+    if mode == "kmeans++":
+        raise NotImplementedError("kmeans++ initialisation is outside the accelerated path")
+    if mode not in ("linear", "forgy") and not (mode == "density" and cdfs is not None):
+        raise Exception(" error mode not found")
+    x, was_numpy = _to_device(layer_weight)
+    if group is not None and mode != "density":
+        raise NotImplementedError("sharded fits take an explicit init: use kmeans.DeviceKMeans")
+    space = _init_space(x, n, bits, mode, cdfs)
+    km = _kmeans.DeviceKMeans(x, np.asarray(space, dtype=np.float32), group=group)
+    model, values = km.fit(want_values=True)
+    shape = tuple(layer_weight.shape)
+    if was_numpy:
+        return values.cpu().numpy().reshape(shape), model
+    return values.view(shape), model

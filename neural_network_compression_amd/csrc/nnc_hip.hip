@@ -1,0 +1,1365 @@
+// nnc_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI (include/nnc.h) for the
+// prune -> k-means -> index re-encode path of neural-network-compression.
+//
+// Everything here is HBM-bound byte/float streaming work (no dense contraction, hence no
+// MFMA): wave64 shuffles for reductions, LDS for the centroid search table and the
+// privatised per-cluster accumulators, 16-byte coalesced global loads, one workgroup per CU.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared  (see build.py).
+// -ffp-contract=off is REQUIRED: mask bits and centroid indices must reproduce the
+// reference's unfused float32 arithmetic (NumPy / scikit-learn on x86).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "nnc.h"
+
+// --------------------------------------------------------------------------------------
+// error plumbing
+// --------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(NNC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+#define LAUNCHCHK(name)                                                                    \
+    do {                                                                                   \
+        hipError_t e_ = hipGetLastError();                                                 \
+        if (e_ != hipSuccess)                                                              \
+            return fail(NNC_EHIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int nnc_version(void) { return NNC_VERSION; }
+extern "C" const char *nnc_last_error(void) { return g_err.c_str(); }
+
+static int g_cu_count = 0;
+static int cu_count()
+{
+    if (g_cu_count == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g_cu_count = prop.multiProcessorCount;
+        if (g_cu_count <= 0) g_cu_count = 256;
+    }
+    return g_cu_count;
+}
+
+extern "C" int nnc_device_info(char *arch_out, size_t arch_len, int *cu_count_out)
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDevice(&dev));
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (arch_out && arch_len) {
+        std::snprintf(arch_out, arch_len, "%s", prop.gcnArchName);
+    }
+    if (cu_count_out) *cu_count_out = prop.multiProcessorCount;
+    return NNC_OK;
+}
+
+static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
+
+// --------------------------------------------------------------------------------------
+// small device helpers
+// --------------------------------------------------------------------------------------
+#define WAVE 64
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    // LDS traffic of one wave executes in order; this only stops the compiler from moving
+    // LDS reads across LDS writes of other lanes of the same wave.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ======================================================================================
+// 1. NumPy-exact float32 reductions
+//
+// np.add.reduce over float32 walks the array in 8192-element buffered chunks; each chunk is
+// summed by the pairwise routine: blocks of <=128 elements with 8 strided accumulators
+// combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), blocks merged as a binary tree (split at
+// n/2 rounded down to a multiple of 8); the chunk sums are folded left to right.  A full
+// 8192 chunk is a perfectly balanced tree of 64 leaves, which maps onto a wave:
+//   * 8 leaves (1024 elements, 4 KiB) per step, loaded as coalesced float4 and transposed
+//     through LDS (leaf stride padded to 136 floats: conflict-free column reads);
+//   * lane (leaf b, accumulator j) adds its 16 elements sequentially;
+//   * xor-shuffles 1,2,4 build the leaf, 8,16,32 the 1024-element node (IEEE addition is
+//     commutative, so both partners of a butterfly hold the same bits);
+//   * the 8 step nodes are merged in registers as a balanced tree.
+// ======================================================================================
+#define LEAF 128
+#define LEAF_PAD 136
+#define STEP_ELEMS 1024
+
+template <bool SQDEV>
+__device__ __forceinline__ float4 xform4(float4 v, float mean)
+{
+    if (SQDEV) {
+        float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+        v.x = a * a; v.y = b * b; v.z = c * c; v.w = d * d;
+    }
+    return v;
+}
+
+template <bool SQDEV>
+__device__ __forceinline__ float xform1(float v, float mean)
+{
+    if (SQDEV) { float a = v - mean; return a * a; }
+    return v;
+}
+
+// one wave per full chunk; 4 waves (4 chunks) per workgroup
+template <bool SQDEV, bool VEC>
+__global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x, int64_t nfull,
+                                                    const float *__restrict__ mean_dev,
+                                                    float *__restrict__ out)
+{
+    __shared__ __align__(16) float lds[4][8 * LEAF_PAD];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *my = lds[wave];
+    const float mean = SQDEV ? *mean_dev : 0.0f;
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nfull; chunk += (int64_t)gridDim.x * 4) {
+        const float *base = x + chunk * NNC_CHUNK;
+        float node[8];
+        float4 cur[4], nxt[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (VEC) cur[r] = reinterpret_cast<const float4 *>(base)[lane + 64 * r];
+            else {
+                const float *p = base + 4 * (lane + 64 * r);
+                cur[r] = make_float4(p[0], p[1], p[2], p[3]);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            if (it < 7) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (VEC) nxt[r] = reinterpret_cast<const float4 *>(base + (it + 1) * STEP_ELEMS)[lane + 64 * r];
+                    else {
+                        const float *p = base + (it + 1) * STEP_ELEMS + 4 * (lane + 64 * r);
+                        nxt[r] = make_float4(p[0], p[1], p[2], p[3]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int e = 4 * (lane + 64 * r); // element index inside the 1024-element step
+                int b = e >> 7, pos = e & 127;
+                *reinterpret_cast<float4 *>(&my[b * LEAF_PAD + pos]) = xform4<SQDEV>(cur[r], mean);
+            }
+            wave_lds_fence();
+            const float *lp = &my[(lane >> 3) * LEAF_PAD + (lane & 7)];
+            float acc = lp[0];
+#pragma unroll
+            for (int t = 1; t < 16; t++) acc = acc + lp[8 * t];
+            wave_lds_fence();
+            acc = acc + __shfl_xor(acc, 1);
+            acc = acc + __shfl_xor(acc, 2);
+            acc = acc + __shfl_xor(acc, 4);
+            acc = acc + __shfl_xor(acc, 8);
+            acc = acc + __shfl_xor(acc, 16);
+            acc = acc + __shfl_xor(acc, 32);
+            node[it] = acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) cur[r] = nxt[r];
+        }
+        float s = ((node[0] + node[1]) + (node[2] + node[3])) + ((node[4] + node[5]) + (node[6] + node[7]));
+        if (lane == 0) out[chunk] = s;
+    }
+}
+
+// The ragged last chunk (m < 8192 elements): thread 0 walks the split tree to list the leaves,
+// 8 lanes per leaf sum them, thread 0 walks the tree again to merge.
+struct PwFrame { int start, len, stage; float left; };
+
+template <bool SQDEV>
+__global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x, int m,
+                                                    const float *__restrict__ mean_dev,
+                                                    float *__restrict__ out)
+{
+    __shared__ int leaf_start[160], leaf_len[160];
+    __shared__ float leaf_sum[160];
+    __shared__ int nleaves_s;
+    const float mean = SQDEV ? *mean_dev : 0.0f;
+    if (threadIdx.x == 0) {
+        int nl = 0, sp = 0;
+        int st_start[24], st_len[24];
+        st_start[0] = 0; st_len[0] = m; sp = 1;
+        // iterative DFS, right child pushed first so leaves come out left to right
+        while (sp > 0) {
+            sp--;
+            int s0 = st_start[sp], l0 = st_len[sp];
+            if (l0 <= LEAF) { leaf_start[nl] = s0; leaf_len[nl] = l0; nl++; }
+            else {
+                int n2 = l0 / 2; n2 -= n2 % 8;
+                st_start[sp] = s0 + n2; st_len[sp] = l0 - n2; sp++;
+                st_start[sp] = s0; st_len[sp] = n2; sp++;
+            }
+        }
+        nleaves_s = nl;
+    }
+    __syncthreads();
+    const int nl = nleaves_s;
+    const int j = threadIdx.x & 7;
+    for (int leaf = threadIdx.x >> 3; leaf < nl; leaf += 32) { // uniform per 8-lane group
+        const float *a = x + leaf_start[leaf];
+        const int len = leaf_len[leaf];
+        float res;
+        if (len < 8) {
+            res = 0.0f;
+            for (int i = 0; i < len; i++) res += xform1<SQDEV>(a[i], mean);
+        } else {
+            float r = xform1<SQDEV>(a[j], mean);
+            const int lim = len - (len % 8);
+            for (int i = 8; i < lim; i += 8) r += xform1<SQDEV>(a[i + j], mean);
+            r = r + __shfl_xor(r, 1);
+            r = r + __shfl_xor(r, 2);
+            r = r + __shfl_xor(r, 4);
+            res = r;
+            for (int i = lim; i < len; i++) res += xform1<SQDEV>(a[i], mean);
+        }
+        if (j == 0) leaf_sum[leaf] = res;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PwFrame st[24];
+        int sp = 1, li = 0;
+        float ret = 0.0f;
+        st[0].start = 0; st[0].len = m; st[0].stage = 0; st[0].left = 0.0f;
+        while (sp > 0) {
+            PwFrame &f = st[sp - 1];
+            if (f.len <= LEAF) { ret = leaf_sum[li++]; sp--; continue; }
+            int n2 = f.len / 2; n2 -= n2 % 8;
+            if (f.stage == 0) {
+                f.stage = 1;
+                st[sp].start = f.start; st[sp].len = n2; st[sp].stage = 0; sp++;
+            } else if (f.stage == 1) {
+                f.left = ret; f.stage = 2;
+                st[sp].start = f.start + n2; st[sp].len = f.len - n2; st[sp].stage = 0; sp++;
+            } else {
+                ret = f.left + ret; sp--;
+            }
+        }
+        *out = ret;
+    }
+}
+
+extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const float *mean_dev,
+                                  float *chunk_out, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x || !chunk_out))) return fail(NNC_EINVAL, "nnc_chunk_sums_f32: null pointer");
+    if (sqdev && !mean_dev) return fail(NNC_EINVAL, "nnc_chunk_sums_f32: sqdev needs mean_dev");
+    if (n == 0) return NNC_OK;
+    const int64_t nfull = n / NNC_CHUNK;
+    const int tail = (int)(n % NNC_CHUNK);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (nfull > 0) {
+        int64_t blocks = (nfull + 3) / 4;
+        int64_t cap = (int64_t)cu_count() * 8;
+        int grid = (int)std::min<int64_t>(blocks, cap);
+        if (sqdev) {
+            if (vec) hipLaunchKernelGGL((k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
+            else hipLaunchKernelGGL((k_chunk_sums<true, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
+        } else {
+            if (vec) hipLaunchKernelGGL((k_chunk_sums<false, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
+            else hipLaunchKernelGGL((k_chunk_sums<false, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
+        }
+        LAUNCHCHK("k_chunk_sums");
+    }
+    if (tail > 0) {
+        if (sqdev) hipLaunchKernelGGL((k_chunk_tail<true>), dim3(1), dim3(256), 0, S(stream), x + nfull * NNC_CHUNK, tail, mean_dev, chunk_out + nfull);
+        else hipLaunchKernelGGL((k_chunk_tail<false>), dim3(1), dim3(256), 0, S(stream), x + nfull * NNC_CHUNK, tail, mean_dev, chunk_out + nfull);
+        LAUNCHCHK("k_chunk_tail");
+    }
+    return NNC_OK;
+}
+
+// Sequential float32 fold of the chunk sums (NumPy's order) by one thread; the other 1023
+// stage the next tile into LDS.
+#define FOLD_TILE 8192
+__global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks, int64_t nchunks, int64_t count,
+                                               int op, const float *__restrict__ scale_dev,
+                                               float *__restrict__ out)
+{
+    __shared__ float buf[FOLD_TILE];
+    float acc = 0.0f;
+    for (int64_t base = 0; base < nchunks; base += FOLD_TILE) {
+        int len = (int)((nchunks - base) < FOLD_TILE ? (nchunks - base) : FOLD_TILE);
+        for (int i = threadIdx.x; i < len; i += 1024) buf[i] = chunks[base + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int i = 0;
+            for (; i + 8 <= len; i += 8) {
+                float v0 = buf[i], v1 = buf[i + 1], v2 = buf[i + 2], v3 = buf[i + 3];
+                float v4 = buf[i + 4], v5 = buf[i + 5], v6 = buf[i + 6], v7 = buf[i + 7];
+                acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
+                acc = acc + v4; acc = acc + v5; acc = acc + v6; acc = acc + v7;
+            }
+            for (; i < len; i++) acc = acc + buf[i];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        float r = acc;
+        if (op == NNC_FOLD_MEAN || op == NNC_FOLD_STD) r = (float)((double)acc / (double)count);
+        if (op == NNC_FOLD_STD) r = (float)sqrt((double)r); // double sqrt then round == correctly rounded sqrtf
+        out[0] = r;
+        if (scale_dev) out[1] = r * (*scale_dev);
+    }
+}
+
+extern "C" int nnc_fold_f32(const float *chunks, int64_t nchunks, int64_t count, int op, const float *scale_dev,
+                            float *out_dev, void *stream)
+{
+    if (!out_dev || nchunks < 0 || (nchunks > 0 && !chunks)) return fail(NNC_EINVAL, "nnc_fold_f32: bad argument");
+    if ((op == NNC_FOLD_MEAN || op == NNC_FOLD_STD) && count <= 0) return fail(NNC_EINVAL, "nnc_fold_f32: count <= 0");
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(1024), 0, S(stream), chunks, nchunks, count, op, scale_dev, out_dev);
+    LAUNCHCHK("k_fold");
+    return NNC_OK;
+}
+
+// ======================================================================================
+// 2. threshold pass: mask = |x| < thr, zero in place, count
+// ======================================================================================
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_threshold(float *__restrict__ x, int64_t n,
+                                                   const float *__restrict__ thr_dev,
+                                                   uint8_t *__restrict__ mask,
+                                                   unsigned long long *__restrict__ nzeroed)
+{
+    const float thr = *thr_dev;
+    unsigned cnt = 0;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if (VEC) {
+        const int64_t nvec = n >> 2;
+        float4 *x4 = reinterpret_cast<float4 *>(x);
+        uchar4 *m4 = reinterpret_cast<uchar4 *>(mask);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            float4 a = x4[v];
+            uchar4 m;
+            m.x = fabsf(a.x) < thr; m.y = fabsf(a.y) < thr; m.z = fabsf(a.z) < thr; m.w = fabsf(a.w) < thr;
+            cnt += m.x + m.y + m.z + m.w;
+            a.x = m.x ? 0.0f : a.x; a.y = m.y ? 0.0f : a.y; a.z = m.z ? 0.0f : a.z; a.w = m.w ? 0.0f : a.w;
+            x4[v] = a;
+            m4[v] = m;
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        float a = x[i];
+        uint8_t m = fabsf(a) < thr;
+        cnt += m;
+        if (m) x[i] = 0.0f;
+        mask[i] = m;
+    }
+    if (nzeroed) {
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nzeroed, (unsigned long long)cnt);
+    }
+}
+
+static int stream_grid(int64_t work_items, int threads, int per_cu)
+{
+    int64_t blocks = (work_items + threads - 1) / threads;
+    int64_t cap = (int64_t)cu_count() * per_cu;
+    if (blocks < 1) blocks = 1;
+    return (int)std::min<int64_t>(blocks, cap);
+}
+
+extern "C" int nnc_threshold_mask_f32(float *x, int64_t n, const float *thr_dev, uint8_t *mask,
+                                      int64_t *nzeroed_dev, void *stream)
+{
+    if (n < 0 || !thr_dev || (n > 0 && (!x || !mask))) return fail(NNC_EINVAL, "nnc_threshold_mask_f32: bad argument");
+    if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
+    if (n == 0) return NNC_OK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
+    int grid = stream_grid((n + 3) / 4, 256, 16);
+    if (vec) hipLaunchKernelGGL((k_threshold<true>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
+    else hipLaunchKernelGGL((k_threshold<false>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
+    LAUNCHCHK("k_threshold");
+    return NNC_OK;
+}
+
+extern "C" size_t nnc_prune_workspace_bytes(int64_t n)
+{
+    int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
+    return (size_t)(nchunks + 64) * sizeof(float);
+}
+
+__global__ void k_set_thr(float q, float *stats)
+{
+    stats[0] = 0.0f;
+    stats[1] = q;
+}
+__global__ void k_set_f32(float v, float *dst) { *dst = v; }
+
+extern "C" int nnc_prune_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev,
+                             int64_t *nzeroed_dev, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n < 0 || !stats_dev || (n > 0 && (!x || !mask))) return fail(NNC_EINVAL, "nnc_prune_f32: bad argument");
+    if (std_smooth) {
+        if (!ws || ws_bytes < nnc_prune_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_prune_f32: workspace too small");
+        if (n == 0) return fail(NNC_EINVAL, "nnc_prune_f32: std of an empty tensor");
+        float *wsf = reinterpret_cast<float *>(ws);
+        float *scal = wsf;          // [0] mean, [1] q
+        float *chunks = wsf + 16;
+        const int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
+        int rc;
+        hipLaunchKernelGGL(k_set_f32, dim3(1), dim3(1), 0, S(stream), q, scal + 1);
+        LAUNCHCHK("k_set_f32");
+        if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, chunks, stream))) return rc;
+        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_MEAN, nullptr, scal, stream))) return rc;
+        if ((rc = nnc_chunk_sums_f32(x, n, 1, scal, chunks, stream))) return rc;
+        // stats = {sigma, sigma * q}
+        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_STD, scal + 1, stats_dev, stream))) return rc;
+    } else {
+        hipLaunchKernelGGL(k_set_thr, dim3(1), dim3(1), 0, S(stream), q, stats_dev);
+        LAUNCHCHK("k_set_thr");
+    }
+    return nnc_threshold_mask_f32(x, n, stats_dev + 1, mask, nzeroed_dev, stream);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_apply_mask(float *__restrict__ x, const uint8_t *__restrict__ mask, int64_t n)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+    if (VEC) {
+        const int64_t nvec = n >> 2;
+        float4 *x4 = reinterpret_cast<float4 *>(x);
+        const uchar4 *m4 = reinterpret_cast<const uchar4 *>(mask);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            uchar4 m = m4[v];
+            if (m.x | m.y | m.z | m.w) {
+                float4 a = x4[v];
+                a.x = m.x ? 0.0f : a.x; a.y = m.y ? 0.0f : a.y; a.z = m.z ? 0.0f : a.z; a.w = m.w ? 0.0f : a.w;
+                x4[v] = a;
+            }
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads)
+        if (mask[i]) x[i] = 0.0f;
+}
+
+extern "C" int nnc_apply_mask_f32(float *x, const uint8_t *mask, int64_t n, void *stream)
+{
+    if (n < 0 || (n > 0 && (!x || !mask))) return fail(NNC_EINVAL, "nnc_apply_mask_f32: bad argument");
+    if (n == 0) return NNC_OK;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
+    int grid = stream_grid((n + 3) / 4, 256, 16);
+    if (vec) hipLaunchKernelGGL((k_apply_mask<true>), dim3(grid), dim3(256), 0, S(stream), x, mask, n);
+    else hipLaunchKernelGGL((k_apply_mask<false>), dim3(grid), dim3(256), 0, S(stream), x, mask, n);
+    LAUNCHCHK("k_apply_mask");
+    return NNC_OK;
+}
+
+// ======================================================================================
+// 3. min / max / count, 31-bin histogram, bincount
+// ======================================================================================
+struct MinMaxPartial { float mn, mx; unsigned long long cnt; };
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int64_t n, int skip_zeros,
+                                                MinMaxPartial *__restrict__ part)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    unsigned long long cnt = 0;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+#define MM1(v) do { float v_ = (v); bool use_ = !(skip_zeros && v_ == 0.0f); if (use_) { mn = fminf(mn, v_); mx = fmaxf(mx, v_); cnt++; } } while (0)
+    if (VEC) {
+        const int64_t nvec = n >> 2;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            float4 a = x4[v];
+            MM1(a.x); MM1(a.y); MM1(a.z); MM1(a.w);
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) MM1(x[i]);
+#undef MM1
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off));
+        mx = fmaxf(mx, __shfl_down(mx, off));
+        cnt += __shfl_down(cnt, off);
+    }
+    __shared__ MinMaxPartial sh[4];
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6].mn = mn; sh[threadIdx.x >> 6].mx = mx; sh[threadIdx.x >> 6].cnt = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinMaxPartial p = sh[0];
+        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; }
+        part[blockIdx.x] = p;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_minmax_final(const MinMaxPartial *__restrict__ part, int nparts,
+                                                      float *__restrict__ out, long long *__restrict__ count)
+{
+    float mn = INFINITY, mx = -INFINITY;
+    unsigned long long cnt = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        mn = fminf(mn, part[i].mn); mx = fmaxf(mx, part[i].mx); cnt += part[i].cnt;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off));
+        mx = fmaxf(mx, __shfl_down(mx, off));
+        cnt += __shfl_down(cnt, off);
+    }
+    __shared__ MinMaxPartial sh[4];
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6].mn = mn; sh[threadIdx.x >> 6].mx = mx; sh[threadIdx.x >> 6].cnt = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinMaxPartial p = sh[0];
+        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; }
+        out[0] = p.mn; out[1] = p.mx;
+        if (count) *count = (long long)p.cnt;
+    }
+}
+
+static int minmax_grid(int64_t n) { return stream_grid((n + 3) / 4, 256, 8); }
+
+extern "C" size_t nnc_minmax_workspace_bytes(int64_t n)
+{
+    (void)n;
+    return (size_t)(cu_count() * 8 + 8) * sizeof(MinMaxPartial);
+}
+
+extern "C" int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev,
+                              void *ws, size_t ws_bytes, void *stream)
+{
+    if (n <= 0 || !x || !out_dev || !ws) return fail(NNC_EINVAL, "nnc_minmax_f32: bad argument (n must be > 0)");
+    if (ws_bytes < nnc_minmax_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_minmax_f32: workspace too small");
+    int grid = minmax_grid(n);
+    MinMaxPartial *part = reinterpret_cast<MinMaxPartial *>(ws);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((k_minmax<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
+    else hipLaunchKernelGGL((k_minmax<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
+    LAUNCHCHK("k_minmax");
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, out_dev, reinterpret_cast<long long *>(count_dev));
+    LAUNCHCHK("k_minmax_final");
+    return NNC_OK;
+}
+
+// bin(x) = #{ steps[i] <= x } - 1 for non-decreasing steps (np.linspace is monotone), which is
+// exactly "steps[b] <= x < steps[b+1]"; x >= steps[31] (the maximum itself) falls in no bin.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_hist31(const float *__restrict__ x, int64_t n, int skip_zeros,
+                                                const float *__restrict__ steps,
+                                                unsigned long long *__restrict__ counts)
+{
+    __shared__ unsigned h[32][32]; // [bin][replica]; replica = lane & 31 -> bank = replica
+    __shared__ float st[32];
+    for (int i = threadIdx.x; i < 32 * 32; i += 256) (&h[0][0])[i] = 0;
+    if (threadIdx.x < 32) st[threadIdx.x] = steps[threadIdx.x];
+    __syncthreads();
+    float s[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) s[i] = st[i];
+    const int rep = threadIdx.x & 31;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+#define H1(v) do { float v_ = (v); if (!(skip_zeros && v_ == 0.0f)) { int c_ = 0; _Pragma("unroll") for (int i = 0; i < 32; i++) c_ += (v_ >= s[i]); if (c_ >= 1 && c_ <= 31) atomicAdd(&h[c_ - 1][rep], 1u); } } while (0)
+    int64_t done = 0;
+    if (VEC) {
+        const int64_t nvec = n >> 2;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            float4 a = x4[v];
+            H1(a.x); H1(a.y); H1(a.z); H1(a.w);
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) H1(x[i]);
+#undef H1
+    __syncthreads();
+    if (threadIdx.x < 31) {
+        unsigned long long t = 0;
+        for (int r = 0; r < 32; r++) t += h[threadIdx.x][r];
+        if (t) atomicAdd(&counts[threadIdx.x], t);
+    }
+}
+
+extern "C" int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps32_dev,
+                              int64_t *counts_dev, void *stream)
+{
+    if (n < 0 || !steps32_dev || !counts_dev || (n > 0 && !x)) return fail(NNC_EINVAL, "nnc_hist31_f32: bad argument");
+    if (n == 0) return NNC_OK;
+    int grid = stream_grid((n + 3) / 4, 256, 8);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((k_hist31<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, steps32_dev, reinterpret_cast<unsigned long long *>(counts_dev));
+    else hipLaunchKernelGGL((k_hist31<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, steps32_dev, reinterpret_cast<unsigned long long *>(counts_dev));
+    LAUNCHCHK("k_hist31");
+    return NNC_OK;
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void k_bincount(const LT *__restrict__ labels, int64_t n, int k,
+                                                  unsigned long long *__restrict__ counts)
+{
+    extern __shared__ unsigned hb[]; // [k][8] replicas
+    for (int i = threadIdx.x; i < k * 8; i += 256) hb[i] = 0;
+    __syncthreads();
+    const int rep = threadIdx.x & 7;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < n; i += nthreads) {
+        int l = labels[i];
+        if (l < k) atomicAdd(&hb[l * 8 + rep], 1u);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) {
+        unsigned long long t = 0;
+        for (int r = 0; r < 8; r++) t += hb[j * 8 + r];
+        if (t) atomicAdd(&counts[j], t);
+    }
+}
+
+extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream)
+{
+    if (n < 0 || k <= 0 || k > NNC_KMAX || !counts_dev || (n > 0 && !labels)) return fail(NNC_EINVAL, "nnc_bincount: bad argument");
+    if (label_bytes != 1 && label_bytes != 2) return fail(NNC_EINVAL, "nnc_bincount: label_bytes must be 1 or 2");
+    if (n == 0) return NNC_OK;
+    int grid = stream_grid(n, 256 * 8, 8);
+    size_t lds = (size_t)k * 8 * sizeof(unsigned);
+    if (label_bytes == 1) hipLaunchKernelGGL((k_bincount<uint8_t>), dim3(grid), dim3(256), lds, S(stream), reinterpret_cast<const uint8_t *>(labels), n, k, reinterpret_cast<unsigned long long *>(counts_dev));
+    else hipLaunchKernelGGL((k_bincount<uint16_t>), dim3(grid), dim3(256), lds, S(stream), reinterpret_cast<const uint16_t *>(labels), n, k, reinterpret_cast<unsigned long long *>(counts_dev));
+    LAUNCHCHK("k_bincount");
+    return NNC_OK;
+}
+
+// ======================================================================================
+// 4. Lloyd k-means
+// ======================================================================================
+//
+// E-step.  scikit-learn labels a sample with the FIRST strict minimum over j of
+//     d_j = fl( fl(c_j*c_j) + fl(-2 * fl(x*c_j)) )        (float32, unfused)
+// on mean-centred x, c.  Evaluating all K of them is ~3 flop x K per weight: compute bound
+// at K = 256 (ten times the HBM time).  In one dimension the winner is the nearest centre
+// except within rounding distance of a midpoint, so each iteration a tiny kernel sorts the
+// centres and builds a uniform grid over [lo, hi] whose cells hold the contiguous range of
+// (sorted) centres that can possibly win for ANY x in the cell, using a rigorous bound
+//     |d_j(float32) - d_j(exact)| <= E = 2.5 * 2^-24 * (c^2 + 2 |x|max |c|)
+// Most cells hold one candidate (label known from the table alone); boundary cells hold two
+// or more and those are evaluated with the exact float32 expression above, ties to the
+// lowest original index.  Result: identical labels to the brute-force scan, ~1 LDS lookup
+// per weight.
+//
+// M-step.  Each weight adds fix(x~) (64-bit fixed point, see nnc.h) and 1 to LDS accumulators
+// of its (sorted) cluster; accumulators are replicated R times ([cluster][replica], replica =
+// lane mod R, so the lanes of a 32-lane group hit 32 different banks and never the same
+// address when R = 32).  Workgroups flush to NSHARD global shards with 64-bit atomics;
+// integer addition makes the result independent of any ordering.
+//
+#define KM_THREADS 1024
+#define KM_NSHARD 16
+#define KM_GMAX 32768
+#define KM_CNT_SAT 63
+
+struct KmTab {
+    float2 cand[NNC_KMAX];   // sorted: (c~, fl(c~*c~))
+    uint16_t orig[NNC_KMAX]; // sorted position -> original centroid index
+    uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 63) << 10)
+};
+
+struct KmWs {
+    nnc_kmeans_status st;
+    nnc_kmeans_params p;
+    int32_t cur;       // which KmTab / centre set is current
+    int32_t glog2, rlog2, pad0;
+    float inv;         // cells per unit: cell = (int)((x~ - lo) * inv)
+    float pad1[3];
+    float c[2][NNC_KMAX];        // centred centres in ORIGINAL index order; [cur] current, [cur^1] previous
+    long long partials[2 * NNC_KMAX]; // sums then counts, original index order (all-reduced across ranks)
+    long long partials_local[2 * NNC_KMAX]; // this rank's own sums/counts of the last accumulated iteration
+    long long shard_sum[KM_NSHARD][NNC_KMAX]; // sorted index order of tab[cur]
+    unsigned long long shard_cnt[KM_NSHARD][NNC_KMAX];
+    KmTab tab[2];
+};
+
+extern "C" size_t nnc_kmeans_workspace_bytes(int32_t k)
+{
+    (void)k;
+    return sizeof(KmWs) + 256;
+}
+
+extern "C" int32_t nnc_fix_shift(float absmax, int64_t n_total)
+{
+    int L = 1;
+    while (((int64_t)1 << L) < n_total && L < 62) L++;
+    if (!(absmax > 0.0f) || !std::isfinite(absmax)) return 0;
+    int P = 0;
+    (void)std::frexp((double)absmax, &P); // absmax = m * 2^P, m in [0.5, 1)
+    return 62 - L - P;
+}
+
+__device__ __forceinline__ long long fix_f32(float v, int Sft)
+{
+    unsigned u = __float_as_uint(v);
+    unsigned e = (u >> 23) & 0xFFu, f = u & 0x7FFFFFu;
+    unsigned long long m = e ? (unsigned long long)(f | 0x800000u) : (unsigned long long)f;
+    int ex = e ? (int)e : 1;
+    int sh = ex - 150 + Sft;
+    unsigned long long q;
+    if (sh >= 0) q = sh > 62 ? 0ull : (m << sh);
+    else {
+        int r = -sh;
+        q = r > 25 ? 0ull : ((m + (1ull << (r - 1))) >> r);
+    }
+    return (u >> 31) ? -(long long)q : (long long)q;
+}
+
+static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
+{
+    int r = p->replicas_log2;
+    if (r < 0) {
+        r = 5;
+        while (r > 0 && (size_t)p->k * ((size_t)1 << r) * 12 > 100 * 1024) r--;
+    }
+    if (r > 5) r = 5;
+    int g = p->grid_log2;
+    if (g <= 0) g = 14;
+    if (g < 6) g = 6;
+    if (g > 15) g = 15;
+    // keep table + accumulators + candidates inside 156 KiB
+    while (g > 6 && ((size_t)2 << g) + (size_t)p->k * ((size_t)1 << r) * 12 + (size_t)NNC_KMAX * 10 > 156 * 1024) g--;
+    *glog2 = g;
+    *rlog2 = r;
+}
+
+static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
+{
+    size_t kp = (size_t)((k + 7) & ~7);
+    size_t b = ((size_t)2 << glog2) + kp * 8 + kp * 2;
+    b = (b + 15) & ~(size_t)15;
+    if (accumulate) b += (size_t)k * ((size_t)1 << rlog2) * 12;
+    return b;
+}
+
+// ---- the streaming kernel ------------------------------------------------------------
+// MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
+template <int MODE, bool VEC, typename LT>
+__global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
+                                                       int which, LT *__restrict__ labels_out,
+                                                       float *__restrict__ quant_out, float *__restrict__ dist_out)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (MODE == 0 && (ws->st.done | ws->st.paused)) return;
+    const int k = ws->p.k;
+    const int glog2 = ws->glog2, rlog2 = ws->rlog2;
+    const int G = 1 << glog2;
+    const int kp = (k + 7) & ~7;
+    const int t = ws->cur ^ (MODE == 1 ? (which & 1) : 0);
+    const KmTab *__restrict__ tab = &ws->tab[t];
+
+    uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
+    float2 *cand_s = reinterpret_cast<float2 *>(smem + ((size_t)2 << glog2));
+    uint16_t *orig_s = reinterpret_cast<uint16_t *>(smem + ((size_t)2 << glog2) + (size_t)kp * 8);
+    size_t off = (((size_t)2 << glog2) + (size_t)kp * 10 + 15) & ~(size_t)15;
+    unsigned long long *sum_s = reinterpret_cast<unsigned long long *>(smem + off);
+    unsigned *cnt_s = reinterpret_cast<unsigned *>(smem + off + ((size_t)k << rlog2) * 8);
+
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab->cell);
+        uint4 *dst = reinterpret_cast<uint4 *>(cell_s);
+        for (int i = threadIdx.x; i < (G >> 3); i += KM_THREADS) dst[i] = src[i];
+        for (int i = threadIdx.x; i < k; i += KM_THREADS) { cand_s[i] = tab->cand[i]; orig_s[i] = tab->orig[i]; }
+        if (MODE == 0) {
+            const int tot = k << rlog2;
+            for (int i = threadIdx.x; i < tot; i += KM_THREADS) { sum_s[i] = 0ull; cnt_s[i] = 0u; }
+        }
+    }
+    __syncthreads();
+
+    const float mean = ws->p.x_mean, lo = ws->p.lo, inv = ws->inv;
+    const int Sft = ws->p.fix_shift;
+    const int rep = threadIdx.x & ((1 << rlog2) - 1);
+    const int gmax = G - 1;
+
+    auto find = [&](float xc) -> int {
+        float tt = (xc - lo) * inv;
+        int cell = (int)tt;
+        cell = min(max(cell, 0), gmax);
+        unsigned e = cell_s[cell];
+        int p = e & 1023;
+        int c = e >> 10;
+        if (c) {
+            if (c == KM_CNT_SAT) c = k - 1 - p;
+            float2 cc = cand_s[p];
+            float bestd = cc.y + (-2.0f * (xc * cc.x));
+            int best = p;
+            for (int i = 1; i <= c; i++) {
+                float2 ci = cand_s[p + i];
+                float d = ci.y + (-2.0f * (xc * ci.x));
+                if (d < bestd || (d == bestd && orig_s[p + i] < orig_s[best])) { bestd = d; best = p + i; }
+            }
+            p = best;
+        }
+        return p;
+    };
+
+    auto one = [&](float xv, int64_t idx) {
+        float xc = xv - mean;
+        int p = find(xc);
+        if (MODE == 0) {
+            long long q = fix_f32(xc, Sft);
+            atomicAdd(&sum_s[(p << rlog2) + rep], (unsigned long long)q);
+            atomicAdd(&cnt_s[(p << rlog2) + rep], 1u);
+        } else {
+            if (labels_out) labels_out[idx] = (LT)orig_s[p];
+            float cv = cand_s[p].x;
+            if (quant_out) quant_out[idx] = cv + mean;
+            if (dist_out) { float dd = xc - cv; dist_out[idx] = dd * dd; }
+        }
+    };
+
+    const int64_t gtid = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
+    const int64_t gthreads = (int64_t)gridDim.x * KM_THREADS;
+    int64_t done = 0;
+    if (VEC) {
+        const int64_t nvec = n >> 2;
+        const float4 *x4 = reinterpret_cast<const float4 *>(x);
+        int64_t v = gtid;
+        for (; v + gthreads < nvec; v += 2 * gthreads) {
+            float4 a = x4[v];
+            float4 b = x4[v + gthreads];
+            if (MODE == 0) {
+                one(a.x, 0); one(a.y, 0); one(a.z, 0); one(a.w, 0);
+                one(b.x, 0); one(b.y, 0); one(b.z, 0); one(b.w, 0);
+            } else {
+                one(a.x, 4 * v); one(a.y, 4 * v + 1); one(a.z, 4 * v + 2); one(a.w, 4 * v + 3);
+                int64_t w = v + gthreads;
+                one(b.x, 4 * w); one(b.y, 4 * w + 1); one(b.z, 4 * w + 2); one(b.w, 4 * w + 3);
+            }
+        }
+        for (; v < nvec; v += gthreads) {
+            float4 a = x4[v];
+            one(a.x, 4 * v); one(a.y, 4 * v + 1); one(a.z, 4 * v + 2); one(a.w, 4 * v + 3);
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + gtid; i < n; i += gthreads) one(x[i], i);
+
+    if (MODE == 0) {
+        __syncthreads();
+        const int R = 1 << rlog2;
+        const int shard = blockIdx.x & (KM_NSHARD - 1);
+        for (int p = threadIdx.x; p < k; p += KM_THREADS) {
+            unsigned long long s = 0, c = 0;
+            for (int r = 0; r < R; r++) { s += sum_s[(p << rlog2) + r]; c += cnt_s[(p << rlog2) + r]; }
+            if (c) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(&ws->shard_sum[shard][p]), s);
+                atomicAdd(&ws->shard_cnt[shard][p], c);
+            }
+        }
+    }
+}
+
+// ---- finalize / prepare kernel (one workgroup) -------------------------------------------
+// NumPy pairwise float32 sum of n <= 8192 values held in LDS, by one thread.
+__device__ float pairwise_serial(const float *a, int n)
+{
+    PwFrame st[24];
+    int sp = 1;
+    float ret = 0.0f;
+    st[0].start = 0; st[0].len = n; st[0].stage = 0; st[0].left = 0.0f;
+    while (sp > 0) {
+        PwFrame &f = st[sp - 1];
+        if (f.len <= LEAF) {
+            const float *b = a + f.start;
+            int len = f.len;
+            float res;
+            if (len < 8) {
+                res = 0.0f;
+                for (int i = 0; i < len; i++) res += b[i];
+            } else {
+                float r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3], r4 = b[4], r5 = b[5], r6 = b[6], r7 = b[7];
+                int lim = len - (len % 8), i;
+                for (i = 8; i < lim; i += 8) {
+                    r0 += b[i]; r1 += b[i + 1]; r2 += b[i + 2]; r3 += b[i + 3];
+                    r4 += b[i + 4]; r5 += b[i + 5]; r6 += b[i + 6]; r7 += b[i + 7];
+                }
+                res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+                for (; i < len; i++) res += b[i];
+            }
+            ret = res; sp--;
+            continue;
+        }
+        int n2 = f.len / 2; n2 -= n2 % 8;
+        if (f.stage == 0) {
+            f.stage = 1;
+            st[sp].start = f.start; st[sp].len = n2; st[sp].stage = 0; sp++;
+        } else if (f.stage == 1) {
+            f.left = ret; f.stage = 2;
+            st[sp].start = f.start + n2; st[sp].len = f.len - n2; st[sp].stage = 0; sp++;
+        } else {
+            ret = f.left + ret; sp--;
+        }
+    }
+    return ret;
+}
+
+#define FIN_INIT 0          // build the table for the initial centres
+#define FIN_FROM_SHARDS 1   // single GPU: reduce shards -> partials -> finalize
+#define FIN_FROM_PARTIALS 2 // multi GPU / resume: partials already hold the global sums
+#define FIN_PACK_ONLY 3     // reduce shards -> partials, nothing else
+
+__global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, int mode, int resume)
+{
+    __shared__ long long sum_o[NNC_KMAX];
+    __shared__ long long cnt_o[NNC_KMAX];
+    __shared__ float cnew[NNC_KMAX];
+    __shared__ float cs[NNC_KMAX];        // sorted centred centres
+    __shared__ uint16_t so[NNC_KMAX];     // sorted -> original
+    __shared__ double zl[NNC_KMAX], zr[NNC_KMAX];
+    __shared__ float sq[NNC_KMAX];
+    __shared__ int sh_i[4];
+    __shared__ long long sh_ll[2];
+
+    const int tid = threadIdx.x;
+    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && ws->st.done) return;
+    if (mode == FIN_FROM_SHARDS && ws->st.paused) return;
+    if (mode == FIN_PACK_ONLY && (ws->st.done | ws->st.paused)) {
+        // no new iteration was accumulated: hand the all-reduce this rank's own sums again,
+        // so that reducing an idle iteration leaves `partials` unchanged
+        const int k2 = 2 * ws->p.k;
+        for (int i = tid; i < k2; i += KM_THREADS) ws->partials[i] = ws->partials_local[i];
+        return;
+    }
+    if (mode == FIN_FROM_PARTIALS && ws->st.paused && !resume) return;
+    const int k = ws->p.k;
+    int cur = ws->cur;
+
+    if (mode == FIN_FROM_SHARDS || mode == FIN_PACK_ONLY) {
+        const KmTab *tab = &ws->tab[cur];
+        for (int p = tid; p < k; p += KM_THREADS) {
+            long long s = 0;
+            unsigned long long c = 0;
+            for (int sh = 0; sh < KM_NSHARD; sh++) {
+                s += ws->shard_sum[sh][p]; c += ws->shard_cnt[sh][p];
+                ws->shard_sum[sh][p] = 0; ws->shard_cnt[sh][p] = 0;
+            }
+            int o = tab->orig[p];
+            sum_o[o] = s; cnt_o[o] = (long long)c;
+            ws->partials[o] = s; ws->partials[k + o] = (long long)c;
+            ws->partials_local[o] = s; ws->partials_local[k + o] = (long long)c;
+        }
+        if (mode == FIN_PACK_ONLY) return;
+    } else if (mode == FIN_FROM_PARTIALS) {
+        for (int j = tid; j < k; j += KM_THREADS) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
+    }
+    __syncthreads();
+
+    if (mode != FIN_INIT) {
+        // ---- empty clusters?
+        if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; sh_ll[0] = -1; }
+        __syncthreads();
+        int my_empty = 0;
+        for (int j = tid; j < k; j += KM_THREADS) my_empty += (cnt_o[j] == 0);
+        if (my_empty) atomicAdd(&sh_i[0], my_empty);
+        __syncthreads();
+        const int n_empty = sh_i[0];
+        if (n_empty > 0 && !resume) {
+            if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = n_empty; }
+            return;
+        }
+        // ---- _average_centers: first index of the largest count, then in index order
+        for (int j = tid; j < k; j += KM_THREADS) atomicMax(&sh_ll[0], cnt_o[j]);
+        __syncthreads();
+        if (tid == 0) sh_i[1] = k;
+        __syncthreads();
+        const long long maxc = sh_ll[0];
+        for (int j = tid; j < k; j += KM_THREADS) if (cnt_o[j] == maxc) atomicMin(&sh_i[1], j);
+        __syncthreads();
+        const int amax = sh_i[1];
+        const int Sft = ws->p.fix_shift;
+        for (int j = tid; j < k; j += KM_THREADS)
+            if (cnt_o[j] > 0) cnew[j] = (float)ldexp((double)sum_o[j] / (double)cnt_o[j], -Sft);
+        __syncthreads();
+        for (int j = tid; j < k; j += KM_THREADS)
+            if (cnt_o[j] <= 0) {
+                // sklearn copies centers[argmax] as it stands: averaged if argmax < j, raw sum otherwise
+                cnew[j] = (amax < j) ? cnew[amax] : (float)ldexp((double)sum_o[amax], -Sft);
+            }
+        __syncthreads();
+        // ---- _center_shift and the tolerance test
+        const float *cold = ws->c[cur];
+        for (int j = tid; j < k; j += KM_THREADS) {
+            float d = cnew[j] - cold[j];
+            float s2 = d * d;
+            float sft = (float)sqrt((double)s2);
+            sq[j] = sft * sft;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float tot = pairwise_serial(sq, k);
+            int iter = ws->st.iter + 1;
+            int done = 0;
+            if (tot <= ws->p.tol) done = 1;
+            else if (iter >= ws->p.max_iter) done = 2;
+            ws->st.iter = iter; ws->st.shift_tot = tot; ws->st.done = done;
+            ws->st.paused = 0; ws->st.n_empty = 0;
+            ws->cur = cur ^ 1;
+        }
+        cur ^= 1;
+        for (int j = tid; j < k; j += KM_THREADS) ws->c[cur][j] = cnew[j];
+        __syncthreads();
+    } else {
+        for (int j = tid; j < k; j += KM_THREADS) cnew[j] = ws->c[cur][j];
+        __syncthreads();
+    }
+
+    // ---- sort the centres (rank by counting; ties by original index)
+    KmTab *tab = &ws->tab[cur];
+    for (int j = tid; j < k; j += KM_THREADS) {
+        float v = cnew[j];
+        int rank = 0;
+        for (int i = 0; i < k; i++) {
+            float u = cnew[i];
+            rank += (u < v) || (u == v && i < j);
+        }
+        cs[rank] = v;
+        so[rank] = (uint16_t)j;
+    }
+    __syncthreads();
+    for (int p = tid; p < k; p += KM_THREADS) {
+        float v = cs[p];
+        tab->cand[p] = make_float2(v, v * v);
+        tab->orig[p] = so[p];
+    }
+    // ---- zone of every centre: the x-interval on which it can be the float32 arg-min
+    const double U = 5.9604644775390625e-08; // 2^-24
+    const double xb = fmax(fabs((double)ws->p.lo), fabs((double)ws->p.hi));
+    for (int p = tid; p < k; p += KM_THREADS) {
+        const double cp = (double)cs[p];
+        double right = INFINITY, left = -INFINITY;
+        for (int q = p + 1; q < k; q++) {
+            const double cq = (double)cs[q];
+            const double mid = 0.5 * (cp + cq);
+            if (mid >= right) break; // every later midpoint is larger still
+            const double delta = cq - cp;
+            if (delta > 0.0) {
+                const double cm = fmax(fabs(cp), fabs(cq));
+                const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
+                right = fmin(right, mid + E / delta);
+            }
+        }
+        for (int q = p - 1; q >= 0; q--) {
+            const double cq = (double)cs[q];
+            const double mid = 0.5 * (cp + cq);
+            if (mid <= left) break;
+            const double delta = cp - cq;
+            if (delta > 0.0) {
+                const double cm = fmax(fabs(cp), fabs(cq));
+                const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
+                left = fmax(left, mid - E / delta);
+            }
+        }
+        zr[p] = right; zl[p] = left;
+    }
+    __syncthreads();
+    // monotone envelopes: zr <- prefix max, zl <- suffix min (serial over k <= 1040)
+    if (tid == 0) { double m = -INFINITY; for (int p = 0; p < k; p++) { m = fmax(m, zr[p]); zr[p] = m; } }
+    if (tid == 64) { double m = INFINITY; for (int p = k - 1; p >= 0; p--) { m = fmin(m, zl[p]); zl[p] = m; } }
+    __syncthreads();
+    // ---- cells: candidate range [plo, phi] per cell
+    const int glog2 = ws->glog2;
+    const int G = 1 << glog2;
+    const double lo = (double)ws->p.lo;
+    const double inv = (double)ws->inv;
+    const int per = (G + KM_THREADS - 1) / KM_THREADS;
+    const int g0 = tid * per;
+    int plo = 0, phi = 0;
+    for (int g = g0; g < g0 + per && g < G; g++) {
+        double a, b;
+        if (inv > 0.0) {
+            a = (g == 0) ? -INFINITY : lo + (double)g * (1.0 - 4.0 * U) / inv;
+            b = (g == G - 1) ? INFINITY : lo + (double)(g + 1) * (1.0 + 4.0 * U) / inv;
+        } else { a = -INFINITY; b = INFINITY; }
+        if (g == g0) {
+            // first centre whose envelope right end reaches a
+            int l = 0, h = k - 1;
+            while (l < h) { int m = (l + h) >> 1; if (zr[m] >= a) h = m; else l = m + 1; }
+            plo = l;
+            // last centre whose envelope left end is <= b
+            l = 0; h = k - 1;
+            while (l < h) { int m = (l + h + 1) >> 1; if (zl[m] <= b) l = m; else h = m - 1; }
+            phi = l;
+        } else {
+            while (plo < k - 1 && !(zr[plo] >= a)) plo++;
+            while (phi < k - 1 && zl[phi + 1] <= b) phi++;
+        }
+        int lo_p = plo, hi_p = phi;
+        if (hi_p < lo_p) { lo_p = 0; hi_p = k - 1; }
+        int c = hi_p - lo_p;
+        if (c >= KM_CNT_SAT) c = KM_CNT_SAT;
+        tab->cell[g] = (uint16_t)(lo_p | (c << 10));
+    }
+}
+
+static int km_check(void *ws, const nnc_kmeans_params *p, const char *who)
+{
+    if (!ws || !p) return fail(NNC_EINVAL, std::string(who) + ": null workspace/params");
+    if (p->k < 1 || p->k > NNC_KMAX - 8) return fail(NNC_EINVAL, std::string(who) + ": k out of range");
+    if (p->n < 0 || p->n_total < p->n) return fail(NNC_EINVAL, std::string(who) + ": bad n / n_total");
+    if ((reinterpret_cast<uintptr_t>(ws) & 15) != 0) return fail(NNC_EINVAL, std::string(who) + ": workspace must be 16-byte aligned");
+    return NNC_OK;
+}
+
+__global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_params p, int glog2, int rlog2, float inv,
+                                                        const float *__restrict__ centers_init)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
+        ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.reserved = 0;
+        ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv;
+    }
+    for (int j = tid; j < p.k; j += KM_THREADS) {
+        float c = centers_init[j] - p.x_mean; // init -= X_mean (float32)
+        ws->c[0][j] = c; ws->c[1][j] = c;
+    }
+    for (int i = tid; i < KM_NSHARD * NNC_KMAX; i += KM_THREADS) {
+        (&ws->shard_sum[0][0])[i] = 0; (&ws->shard_cnt[0][0])[i] = 0;
+    }
+    for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
+}
+
+extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
+                               void *stream)
+{
+    int rc = km_check(ws, p, "nnc_kmeans_init");
+    if (rc) return rc;
+    if (!centers_init_dev) return fail(NNC_EINVAL, "nnc_kmeans_init: null centers");
+    if (ws_bytes < nnc_kmeans_workspace_bytes(p->k)) return fail(NNC_ENOSPACE, "nnc_kmeans_init: workspace too small");
+    int glog2, rlog2;
+    km_defaults(p, &glog2, &rlog2);
+    // cells per unit, a hair under G / (hi - lo) so that x~ = hi still lands in the last cell
+    float inv = 0.0f;
+    double range = (double)p->hi - (double)p->lo;
+    if (range > 0.0) inv = (float)(((double)(1 << glog2)) / range * (1.0 - 1.0 / 1048576.0));
+    if (!std::isfinite(inv)) inv = 0.0f;
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    hipLaunchKernelGGL(k_km_init, dim3(1), dim3(KM_THREADS), 0, S(stream), w, *p, glog2, rlog2, inv, centers_init_dev);
+    LAUNCHCHK("k_km_init");
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, FIN_INIT, 0);
+    LAUNCHCHK("k_finalize(init)");
+    return NNC_OK;
+}
+
+static int km_grid(int64_t n)
+{
+    int64_t blocks = ((n + 3) / 4 + KM_THREADS - 1) / KM_THREADS;
+    if (blocks < 1) blocks = 1;
+    return (int)std::min<int64_t>(blocks, cu_count());
+}
+
+static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream)
+{
+    int glog2, rlog2;
+    km_defaults(p, &glog2, &rlog2);
+    size_t lds = km_lds_bytes(p->k, glog2, rlog2, true);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    int grid = km_grid(p->n);
+    if (p->n == 0) return NNC_OK;
+    if (vec) hipLaunchKernelGGL((k_assign<0, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    else hipLaunchKernelGGL((k_assign<0, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    LAUNCHCHK("k_assign<accumulate>");
+    return NNC_OK;
+}
+
+static bool g_lds_attr_set = false;
+static int km_set_lds_attr()
+{
+    if (g_lds_attr_set) return NNC_OK;
+    const int maxlds = 160 * 1024;
+#define SETATTR(fn) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds))
+    SETATTR((k_assign<0, true, uint8_t>));
+    SETATTR((k_assign<0, false, uint8_t>));
+    SETATTR((k_assign<1, true, uint8_t>));
+    SETATTR((k_assign<1, false, uint8_t>));
+    SETATTR((k_assign<1, true, uint16_t>));
+    SETATTR((k_assign<1, false, uint16_t>));
+#undef SETATTR
+    g_lds_attr_set = true;
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_accumulate(const float *x, void *ws, const nnc_kmeans_params *pp, void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_accumulate");
+    if (rc) return rc;
+    const nnc_kmeans_params p = *pp;
+    if (p.n > 0 && !x) return fail(NNC_EINVAL, "nnc_kmeans_accumulate: null x");
+    if ((rc = km_set_lds_attr())) return rc;
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, FIN_PACK_ONLY, 0);
+    LAUNCHCHK("k_finalize(pack)");
+    return NNC_OK;
+}
+
+extern "C" int64_t *nnc_kmeans_partials(void *ws)
+{
+    if (!ws) return nullptr;
+    return reinterpret_cast<int64_t *>(reinterpret_cast<KmWs *>(ws)->partials);
+}
+
+extern "C" int nnc_kmeans_finalize(void *ws, int resume, void *stream)
+{
+    if (!ws) return fail(NNC_EINVAL, "nnc_kmeans_finalize: null workspace");
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), FIN_FROM_PARTIALS, resume ? 1 : 0);
+    LAUNCHCHK("k_finalize");
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_iterate");
+    if (rc) return rc;
+    const nnc_kmeans_params p = *pp;
+    if (p.n > 0 && !x) return fail(NNC_EINVAL, "nnc_kmeans_iterate: null x");
+    if (p.n != p.n_total) return fail(NNC_EINVAL, "nnc_kmeans_iterate: sharded vector (n != n_total) needs accumulate / all-reduce / finalize");
+    if ((rc = km_set_lds_attr())) return rc;
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    for (int i = 0; i < iters; i++) {
+        if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, FIN_FROM_SHARDS, 0);
+        LAUNCHCHK("k_finalize(shards)");
+    }
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, void *stream)
+{
+    if (!ws || !host_out) return fail(NNC_EINVAL, "nnc_kmeans_status_async: null pointer");
+    HIPCHK(hipMemcpyAsync(host_out, &reinterpret_cast<KmWs *>(ws)->st, sizeof(nnc_kmeans_status), hipMemcpyDeviceToHost, S(stream)));
+    return NNC_OK;
+}
+
+__global__ void k_set_done(KmWs *ws, int code) { ws->st.done = code; }
+
+extern "C" int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream)
+{
+    if (!ws) return fail(NNC_EINVAL, "nnc_kmeans_set_done: null workspace");
+    hipLaunchKernelGGL(k_set_done, dim3(1), dim3(1), 0, S(stream), reinterpret_cast<KmWs *>(ws), done_code);
+    LAUNCHCHK("k_set_done");
+    return NNC_OK;
+}
+
+__global__ void k_get_centers(const KmWs *ws, int which, int centred, float *out)
+{
+    const int k = ws->p.k;
+    const float *c = ws->c[ws->cur ^ (which & 1)];
+    const float mean = ws->p.x_mean;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) out[j] = centred ? c[j] : (c[j] + mean);
+}
+
+extern "C" int nnc_kmeans_get_centers(void *ws, int which, int centred, float *out_dev, void *stream)
+{
+    if (!ws || !out_dev) return fail(NNC_EINVAL, "nnc_kmeans_get_centers: null pointer");
+    hipLaunchKernelGGL(k_get_centers, dim3(1), dim3(256), 0, S(stream), reinterpret_cast<const KmWs *>(ws), which, centred, out_dev);
+    LAUNCHCHK("k_get_centers");
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int which, void *labels_out,
+                                 int label_bytes, float *quant_out, float *dist_out, void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_assign");
+    if (rc) return rc;
+    const nnc_kmeans_params p = *pp;
+    if (p.n > 0 && !x) return fail(NNC_EINVAL, "nnc_kmeans_assign: null x");
+    if (labels_out && label_bytes != 1 && label_bytes != 2) return fail(NNC_EINVAL, "nnc_kmeans_assign: label_bytes must be 1 or 2");
+    if (labels_out && label_bytes == 1 && p.k > 256) return fail(NNC_EINVAL, "nnc_kmeans_assign: k > 256 needs 2-byte labels");
+    if (p.n == 0) return NNC_OK;
+    if ((rc = km_set_lds_attr())) return rc;
+    int glog2, rlog2;
+    km_defaults(&p, &glog2, &rlog2);
+    size_t lds = km_lds_bytes(p.k, glog2, rlog2, false);
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    int grid = km_grid(p.n);
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if (label_bytes == 2) {
+        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out);
+        else hipLaunchKernelGGL((k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out);
+    } else {
+        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out);
+        else hipLaunchKernelGGL((k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out);
+    }
+    LAUNCHCHK("k_assign<labels>");
+    return NNC_OK;
+}
+
+// ======================================================================================
+// 5. Huffman code lengths (host)
+// ======================================================================================
+extern "C" int nnc_huffman_lengths(const int64_t *counts, int32_t k, uint8_t *lengths_out, int64_t *hist_out,
+                                   int64_t *total_bits_out)
+{
+    if (!counts || k <= 0 || !lengths_out) return fail(NNC_EINVAL, "nnc_huffman_lengths: bad argument");
+    struct Node { int64_t w; int32_t minsym; int32_t left, right; };
+    std::vector<Node> nodes;
+    nodes.reserve(2 * (size_t)k);
+    auto cmp = [&](int a, int b) {
+        if (nodes[a].w != nodes[b].w) return nodes[a].w > nodes[b].w;
+        return nodes[a].minsym > nodes[b].minsym;
+    };
+    std::priority_queue<int, std::vector<int>, decltype(cmp)> pq(cmp);
+    for (int s = 0; s < k; s++) {
+        lengths_out[s] = 0;
+        if (counts[s] < 0) return fail(NNC_EINVAL, "nnc_huffman_lengths: negative count");
+        if (counts[s] > 0) { nodes.push_back({counts[s], s, -1, -1}); pq.push((int)nodes.size() - 1); }
+    }
+    if (pq.size() == 1) lengths_out[nodes[pq.top()].minsym] = 1;
+    else if (pq.size() > 1) {
+        while (pq.size() > 1) {
+            int a = pq.top(); pq.pop();
+            int b = pq.top(); pq.pop();
+            nodes.push_back({nodes[a].w + nodes[b].w, std::min(nodes[a].minsym, nodes[b].minsym), a, b});
+            pq.push((int)nodes.size() - 1);
+        }
+        // depth of every leaf
+        std::vector<std::pair<int, int>> stack;
+        stack.push_back({pq.top(), 0});
+        while (!stack.empty()) {
+            auto [n, d] = stack.back();
+            stack.pop_back();
+            if (nodes[n].left < 0) { lengths_out[nodes[n].minsym] = (uint8_t)std::min(d, 255); continue; }
+            stack.push_back({nodes[n].left, d + 1});
+            stack.push_back({nodes[n].right, d + 1});
+        }
+    }
+    if (hist_out) for (int i = 0; i < 65; i++) hist_out[i] = 0;
+    int64_t total = 0;
+    for (int s = 0; s < k; s++) {
+        if (hist_out) hist_out[std::min<int>(lengths_out[s], 64)]++;
+        total += (int64_t)lengths_out[s] * counts[s];
+    }
+    if (total_bits_out) *total_bits_out = total;
+    return NNC_OK;
+}

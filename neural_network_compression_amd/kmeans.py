@@ -1,0 +1,267 @@
+"""Lloyd k-means on a flattened weight vector resident in HBM.
+
+Host-side driver of the device state machine in csrc/nnc_hip.hip (nnc_kmeans_*): it is
+the counterpart of ``KMeans(n_clusters=K, init=space.reshape(-1,1), n_init=1,
+algorithm="full").fit(w.reshape(-1,1))`` as the reference calls it
+(neural_network_compression/common/utility.py:237-238), following scikit-learn's
+``KMeans.fit`` / ``_kmeans_single_lloyd`` (sklearn/cluster/_kmeans.py:1427-1554, 624-752):
+
+  tol = float32(var(X)) * float32(1e-4); X -= mean; init -= mean
+  repeat <= 300 times: E-step, M-step (+ empty-cluster relocation), centre shift;
+      stop if labels == previous labels, else if sum(shift^2) <= tol
+  one more E-step unless the stop was the label test; centres += mean
+
+Per-cluster sums are exact fixed-point integers (include/nnc.h), so the result does not
+depend on block order or on how many GPUs share the vector.  With ``group`` (a
+torch.distributed process group, one rank per GPU) every rank holds one contiguous shard
+starting on a multiple of 8192 elements and the only data-path exchange is one small
+all-reduce (2K int64) per iteration.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import ops
+
+MAX_ITER = 300  # scikit-learn default, which the reference does not override
+TOL = 1e-4
+
+
+class QuantizedModel:
+    """What the reference reads from the fitted scikit-learn model (utility.py:239):
+    ``cluster_centers_`` (K,1) float32, ``labels_`` (N,) int32, ``n_iter_``."""
+
+    def __init__(self, centers: np.ndarray, labels_compact: torch.Tensor, n_iter: int, n_relocations: int,
+                 stop: str):
+        self.cluster_centers_ = centers.reshape(-1, 1)
+        self.labels_compact_ = labels_compact  # device uint8 (K<=256) or int16 storage of uint16
+        self.n_iter_ = int(n_iter)
+        self.n_relocations_ = int(n_relocations)
+        self.stop_reason_ = stop
+        self._labels_np = None
+
+    def labels_device(self) -> torch.Tensor:
+        """int32 centroid indices on the device."""
+        lc = self.labels_compact_
+        if lc.dtype == torch.uint8:
+            return lc.to(torch.int32)
+        return lc.to(torch.int32) & 0xFFFF
+
+    @property
+    def labels_(self) -> np.ndarray:
+        if self._labels_np is None:
+            self._labels_np = self.labels_device().cpu().numpy()
+        return self._labels_np
+
+
+def _allreduce_(t: torch.Tensor, op, group):
+    import torch.distributed as dist
+
+    dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+class DeviceKMeans:
+    """One fit = one instance.  ``x`` float32, 1-D, contiguous, CUDA."""
+
+    def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
+                 batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1):
+        if x.dim() != 1:
+            x = x.reshape(-1)
+        ops._require_cuda(x, "x", torch.float32)
+        self.L = nat.load()
+        self.x = x
+        self.group = group
+        self.batch = max(1, int(batch))
+        self.dev = x.device
+        self.stream = ops._stream(x)
+        init = np.ascontiguousarray(np.asarray(init, dtype=np.float32).reshape(-1))
+        self.k = int(init.size)
+        if not (1 <= self.k <= nat.NNC_KMAX - 8):
+            raise ValueError(f"number of centroids {self.k} out of range")
+        n = x.numel()
+        n_total = n
+        if group is not None:
+            import torch.distributed as dist
+
+            t = torch.tensor([n], dtype=torch.int64, device=self.dev)
+            _allreduce_(t, dist.ReduceOp.SUM, group)
+            n_total = int(t.item())
+        if n_total < self.k:
+            raise ValueError(f"n_samples={n_total} should be >= n_clusters={self.k}.")
+        self.n, self.n_total = n, n_total
+
+        # ---- NumPy-exact mean / var, min / max  (one host sync for the whole fit set-up)
+        mean_d, var_d, _ = ops.moments(x, n_total, group)
+        mm, _ = ops.minmax(x) if n > 0 else (torch.tensor([np.inf, -np.inf], dtype=torch.float32, device=self.dev), None)
+        if group is not None:
+            import torch.distributed as dist
+
+            mn, mx = mm[0:1].clone(), mm[1:2].clone()
+            _allreduce_(mn, dist.ReduceOp.MIN, group)
+            _allreduce_(mx, dist.ReduceOp.MAX, group)
+            mm = torch.cat([mn, mx])
+        host = torch.cat([mean_d, var_d, mm]).cpu().numpy()
+        mean, var, xmin, xmax = (np.float32(v) for v in host)
+        self.x_mean = mean
+        self.tol_ = np.float32(var * np.float32(tol))  # np.mean(np.var(X, axis=0)) * tol, float32
+        lo, hi = np.float32(xmin - mean), np.float32(xmax - mean)  # exact range of the centred data
+        absmax = float(max(abs(lo), abs(hi)))
+        self.fix_shift = ops.fix_shift(absmax, n_total)
+
+        self.p = nat.KMeansParams(n=n, n_total=n_total, k=self.k, max_iter=int(max_iter), fix_shift=self.fix_shift,
+                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), reserved=0,
+                                  x_mean=float(mean), tol=float(self.tol_), lo=float(lo), hi=float(hi))
+        self.ws_bytes = self.L.nnc_kmeans_workspace_bytes(self.k)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
+        init_d = torch.from_numpy(init).to(self.dev)
+        nat.check(self.L.nnc_kmeans_init(self.ws.data_ptr(), self.ws_bytes, ctypes.byref(self.p), init_d.data_ptr(), self.stream))
+        pptr = self.L.nnc_kmeans_partials(self.ws.data_ptr())
+        # view of the device partials (2K int64) inside the workspace, for the all-reduce / relocation edits
+        off = pptr - self.ws.data_ptr()
+        self.partials = self.ws[off: off + 16 * self.k].view(torch.int64)
+        self.n_relocations = 0
+        self._status_host = nat.KMeansStatus()
+
+    # -------------------------------------------------------------- low-level steps
+    def status(self) -> nat.KMeansStatus:
+        nat.check(self.L.nnc_kmeans_status_async(self.ws.data_ptr(), ctypes.byref(self._status_host), self.stream))
+        torch.cuda.current_stream(self.dev).synchronize()
+        return self._status_host
+
+    def iterate(self, iters: int):
+        """Enqueue `iters` Lloyd iterations (no host sync)."""
+        if self.group is None:
+            nat.check(self.L.nnc_kmeans_iterate(self.x.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters), self.stream))
+            return
+        import torch.distributed as dist
+
+        for _ in range(int(iters)):
+            nat.check(self.L.nnc_kmeans_accumulate(self.x.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), self.stream))
+            dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
+            nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 0, self.stream))
+
+    def assign(self, which: int = 0, labels: bool = True, values: bool = False, distances: bool = False):
+        lab = q = d = None
+        lb = 1 if self.k <= 256 else 2
+        if labels:
+            lab = torch.empty(self.n, dtype=torch.uint8 if lb == 1 else torch.int16, device=self.dev)
+        if values:
+            q = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        if distances:
+            d = torch.empty(self.n, dtype=torch.float32, device=self.dev)
+        nat.check(self.L.nnc_kmeans_assign(self.x.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(which),
+                                           ops._ptr(lab), lb, ops._ptr(q), ops._ptr(d), self.stream))
+        return lab, q, d
+
+    def centers(self, which: int = 0, centred: bool = False) -> np.ndarray:
+        out = torch.empty(self.k, dtype=torch.float32, device=self.dev)
+        nat.check(self.L.nnc_kmeans_get_centers(self.ws.data_ptr(), int(which), 1 if centred else 0, out.data_ptr(), self.stream))
+        return out.cpu().numpy()
+
+    # -------------------------------------------------------------- empty-cluster relocation
+    def _relocate_and_resume(self, st) -> bool:
+        """scikit-learn's _relocate_empty_clusters_dense (_k_means_common.pyx:167-211) for a
+        paused iteration, then resume the finalize step.  Returns True when the labels of
+        this iteration equal those of the previous one (strict convergence).
+
+        The n_empty farthest samples are picked with numpy.argpartition on the host, because
+        which empty cluster receives which sample is defined by that routine's internal
+        order; the distances themselves come from the device."""
+        n_empty = int(st.n_empty)
+        lab, _, d = self.assign(which=0, labels=True, distances=True)
+        strict = False
+        if st.iter >= 1:
+            prev, _, _ = self.assign(which=1, labels=True)
+            same = torch.equal(lab, prev)
+            if self.group is not None:
+                import torch.distributed as dist
+
+                flag = torch.tensor([0 if same else 1], dtype=torch.int64, device=self.dev)
+                _allreduce_(flag, dist.ReduceOp.SUM, self.group)
+                same = int(flag.item()) == 0
+            strict = bool(same)
+        if self.group is None:
+            d_all, x_src, lab_src, base = d, self.x, lab, 0
+        else:
+            d_all, x_src, lab_src, base = self._gather_for_relocation(d, lab)
+        d_host = d_all.cpu().numpy()
+        far = np.argpartition(d_host, -n_empty)[: -n_empty - 1: -1]
+        if np.max(d_host) != 0:
+            part = self.partials.cpu().numpy().copy()
+            sums, counts = part[: self.k], part[self.k:]
+            empty = np.where(counts == 0)[0]
+            idx_t = torch.from_numpy(far.astype(np.int64)).to(self.dev)
+            xs = x_src[idx_t].cpu().numpy().astype(np.float32)
+            ls = lab_src[idx_t].to(torch.int32).cpu().numpy() & 0xFFFF
+            for i in range(n_empty):
+                new, old = int(empty[i]), int(ls[i])
+                v = ops.fix_f32(np.float32(xs[i] - self.x_mean), self.fix_shift)
+                sums[old] -= v
+                sums[new] = v
+                counts[new] = 1
+                counts[old] -= 1
+            self.partials.copy_(torch.from_numpy(part).to(self.dev))
+        nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 1, self.stream))
+        self.n_relocations += 1
+        self._strict_labels = lab if strict else None
+        return strict
+
+    def _gather_for_relocation(self, d, lab):
+        import torch.distributed as dist
+
+        world = dist.get_world_size(self.group)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([self.n], dtype=torch.int64, device=self.dev), group=self.group)
+        sizes = [int(s.item()) for s in sizes]
+        mx = max(sizes)
+
+        def gather(t, dtype):
+            pad = torch.zeros(mx, dtype=dtype, device=self.dev)
+            pad[: self.n] = t.to(dtype)
+            bufs = [torch.empty(mx, dtype=dtype, device=self.dev) for _ in range(world)]
+            dist.all_gather(bufs, pad, group=self.group)
+            return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+
+        return gather(d, torch.float32), gather(self.x, torch.float32), gather(lab.to(torch.int32) & 0xFFFF, torch.int32), 0
+
+    # -------------------------------------------------------------- the fit loop
+    def fit(self, want_values: bool = True):
+        """Runs to convergence.  Returns (QuantizedModel, values tensor or None) where
+        values = cluster_centers_[labels_] as a device float32 vector (utility.py:239)."""
+        strict_labels = None
+        batch = self.batch
+        while True:
+            self.iterate(batch)
+            st = self.status()
+            if st.paused:
+                # an empty cluster stopped the device loop inside this batch: relocate on the
+                # host, resume that iteration, then go on one iteration at a time for a while
+                strict = self._relocate_and_resume(st)
+                if strict:
+                    nat.check(self.L.nnc_kmeans_set_done(self.ws.data_ptr(), 3, self.stream))
+                    strict_labels = self._strict_labels
+                st = self.status()
+                batch = 1
+            else:
+                batch = min(self.batch, batch * 2)
+            if st.done:
+                break
+        stop = {1: "tol", 2: "max_iter", 3: "strict"}.get(int(st.done), "?")
+        centers = self.centers(which=0, centred=False)
+        if strict_labels is not None:
+            # label-equality stop: scikit-learn keeps the labels of that iteration and does
+            # not run another E-step (_kmeans.py:717-722, 736)
+            lab = strict_labels
+            vals = None
+            if want_values:
+                idx = lab.to(torch.int64) if lab.dtype == torch.uint8 else (lab.to(torch.int64) & 0xFFFF)
+                vals = torch.from_numpy(centers).to(self.dev)[idx]
+        else:
+            lab, vals, _ = self.assign(which=0, labels=True, values=want_values)
+        model = QuantizedModel(centers, lab, st.iter, self.n_relocations, stop)
+        return model, vals

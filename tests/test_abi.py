@@ -1,0 +1,98 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/nnc.h
+declares, and its host-only entry points agree with the oracle.  No GPU compute calls."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from neural_network_compression_amd import _native as nat
+from neural_network_compression_amd import build as nbuild
+from oracle import oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    nbuild.build_native()
+    return nat.load()
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "nnc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nnc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    syms = header_symbols()
+    assert len(syms) >= 25
+    raw = ctypes.CDLL(nat.lib_path())
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in nnc.h but not exported"
+        assert s in nat.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(nat.SIGNATURES) == set(syms)
+    assert lib.nnc_version() == 100
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setattr(nat._build, "LIB", "/nonexistent/libnnc_hip.so")
+    with pytest.raises(nat.NativeLibraryError, match="no CPU fallback"):
+        nat.load()
+
+
+def test_struct_layouts():
+    assert ctypes.sizeof(nat.KMeansParams) == 56
+    assert ctypes.sizeof(nat.KMeansStatus) == 32
+
+
+def test_fix_shift_rule(lib):
+    from neural_network_compression_amd import ops
+    for absmax, n in [(0.2288, 235200), (1.0, 25_000_000), (3e-5, 1000), (0.0, 10), (123.5, 124_000_000), (0.5, 2)]:
+        s = lib.nnc_fix_shift(absmax, n)
+        assert s == orc.fix_shift(float(np.float32(absmax)), n) == ops.fix_shift(float(np.float32(absmax)), n)
+
+
+def test_host_fix_mirror_matches_oracle():
+    from neural_network_compression_amd import ops
+    rng = np.random.RandomState(0)
+    vals = np.concatenate([rng.randn(2000).astype(np.float32) * 0.05,
+                           np.array([0.0, -0.0, 1e-45, -1e-38, 0.25, -0.25, 3e-9], dtype=np.float32)])
+    for S in (30, 39, 44, 60, 100):
+        for v in vals[:300] if S != 39 else vals:
+            assert ops.fix_f32(v, S) == orc.fix(v, S)
+
+
+def test_huffman_host_entry_matches_oracle(lib):
+    from neural_network_compression_amd import ops
+    rng = np.random.RandomState(1)
+    for k in (1, 2, 5, 16, 33, 256, 257):
+        counts = rng.randint(0, 1000, size=k).astype(np.int64)
+        counts[rng.randint(0, k)] += 1  # at least one used symbol
+        if k > 4:
+            counts[1] = counts[2]  # ties
+            counts[3] = 0
+        lengths, hist, total = ops.huffman_lengths(counts)
+        ol, oh, ot = orc.huffman_lengths(counts)
+        assert np.array_equal(lengths, ol), k
+        assert np.array_equal(hist, oh) and total == ot
+        # Kraft equality for a full binary code tree
+        used = lengths[lengths > 0].astype(int)
+        if used.size > 1:
+            assert abs(sum(2.0 ** -l for l in used) - 1.0) < 1e-12
+
+
+def test_forgy_draw_consumes_rng_like_the_reference():
+    a = np.arange(1000, dtype=np.float32) * 0.5
+    np.random.seed(7)
+    ref = np.random.choice(a, size=32)
+    np.random.seed(7)
+    idx = np.random.randint(0, a.size, size=32)
+    assert np.array_equal(a[idx], ref)
+    nxt = np.random.rand()
+    np.random.seed(7)
+    np.random.choice(a, size=32)
+    assert nxt == np.random.rand()

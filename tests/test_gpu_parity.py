@@ -1,0 +1,357 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(ctypes -> csrc/libnnc_hip.so), against the CPU oracle and the reference's golden vectors.
+
+Bars: bit-exact masks, bit-exact centroid indices, bit-exact centres against the oracle in
+its order-independent accumulation mode "B"; against the reference's own float32 running
+sums (goldens, mode "A") the centres agree to the reference's summation error.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from neural_network_compression_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits(x):
+    return int(np.array([x], dtype=np.float32).view(np.uint32)[0])
+
+
+@pytest.fixture(scope="module")
+def nnc():
+    assert torch.cuda.is_available(), "these tests need the GPU"
+    from neural_network_compression_amd import _native, kmeans, ops
+    from neural_network_compression_amd.common import utility
+
+    _native.load()  # fails loudly if the HIP library is missing
+
+    class NS:
+        pass
+
+    ns = NS()
+    ns.ops, ns.kmeans, ns.utility, ns.native = ops, kmeans, utility, _native
+    ns.dev = torch.device("cuda:0")
+    arch, cus = ops.device_info()
+    assert arch.startswith("gfx950"), arch
+    return ns
+
+
+def dev(nnc, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(nnc.dev)
+
+
+# ------------------------------------------------------------------ reductions
+@pytest.mark.parametrize("n", [1, 7, 8, 100, 129, 1000, 8191, 8192, 8193, 16384, 24577, 100003, 235200,
+                               (1 << 20) + 4099, 3_000_001])
+def test_moments_bit_exact(nnc, n):
+    w = synth.weights((n,), 31 + n % 1000, scale=0.3) + np.float32(0.01)
+    mean, var, std = nnc.ops.moments(dev(nnc, w))
+    assert bits(mean.cpu().numpy()[0]) == bits(orc.np_mean(w))
+    assert bits(var.cpu().numpy()[0]) == bits(orc.np_var(w))
+    assert bits(std.cpu().numpy()[0]) == bits(orc.np_std(w))
+    assert bits(std.cpu().numpy()[0]) == bits(np.std(w))  # and NumPy itself
+
+
+def test_moments_unaligned_view(nnc):
+    w = synth.weights((50001,), 5)
+    t = dev(nnc, w)[1:]  # 4-byte aligned only
+    mean, var, std = nnc.ops.moments(t.contiguous() if not t.is_contiguous() else t)
+    assert bits(std.cpu().numpy()[0]) == bits(orc.np_std(w[1:]))
+
+
+# ------------------------------------------------------------------ prune
+def test_prune_goldens(nnc, gold):
+    keys = gold.keys("prune/")
+    assert len(keys) > 100
+    for key in keys:
+        c = gold.cases[key]
+        w = synth.weights(tuple(c["shape"]), c["seed"])
+        mask = nnc.utility.prune_weigth(w, threshold=c["q"], std_smooth=c["std_smooth"])
+        assert mask.dtype == np.bool_ and mask.shape == tuple(c["shape"]), key
+        assert int(mask.sum()) == c["nzeroed"], key
+        assert sha(np.packbits(mask.ravel())) == c["mask_sha256"], key
+        assert sha(w) == c["pruned_sha256"], key  # argument mutated in place, like the reference
+
+
+def test_prune_device_resident_and_stats(nnc):
+    w = synth.weights((784, 300), 2000)
+    t = dev(nnc, w)
+    mask = nnc.utility.prune_weigth(t, 1, True)
+    wc = w.copy()
+    omask = orc.prune_weigth(wc, 1, True)
+    assert mask.dtype == torch.bool and mask.shape == t.shape
+    assert np.array_equal(mask.cpu().numpy(), omask)
+    assert np.array_equal(t.cpu().numpy(), wc)
+    # sigma/threshold/zero count straight from the operator
+    t2 = dev(nnc, w)
+    m2, stats, nz = nnc.ops.prune_(t2, 0.5, True)
+    sigma = orc.np_std(w)
+    assert bits(stats.cpu().numpy()[0]) == bits(sigma)
+    assert bits(stats.cpu().numpy()[1]) == bits(np.float32(sigma * np.float32(0.5)))
+    assert int(nz.item()) == int(m2.sum().item())
+
+
+def test_prune_threshold_kinds(nnc):
+    w0 = synth.weights((3000,), 11)
+    for thr, smooth in [(np.float64(0.7), True), (np.float32(0.7), True), (0.7, True), (np.float64(0.03), False), (1, True)]:
+        w = w0.copy()
+        ref = w0.copy()
+        t = np.std(ref) * thr if smooth else thr
+        rmask = np.abs(ref) < t
+        mask = nnc.utility.prune_weigth(w, thr, smooth)
+        assert np.array_equal(mask, rmask), (thr, smooth)
+
+
+def test_apply_mask(nnc):
+    w = synth.weights((100_003,), 3)
+    mask = np.abs(w) < 0.03
+    t = dev(nnc, w)
+    nnc.ops.apply_mask_(t, dev(nnc, mask.view(np.uint8)))
+    e = w.copy()
+    e[mask] = 0
+    assert np.array_equal(t.cpu().numpy(), e)
+
+
+# ------------------------------------------------------------------ CDF
+def test_cdf_goldens(nnc, gold):
+    for key in gold.keys("cdf/"):
+        c = gold.cases[key]
+        w = synth.weights(tuple(c["shape"]), c["seed"])
+        orc.prune_weigth(w, c["q"], True)
+        flat = w.ravel()
+        nz = flat[flat != 0]
+        xnew, cdf = nnc.utility.get_weight_distribution(nz)
+        assert np.array_equal(xnew, gold.arr(c["xnew"])), key
+        assert np.array_equal(cdf, gold.arr(c["cdf"])), key
+        # skipping the zeros on the device == stripping them first
+        x2, c2 = nnc.utility.get_weight_distribution(dev(nnc, w), skip_zeros=True)
+        assert np.array_equal(x2, xnew) and np.array_equal(c2, cdf), key
+
+
+# ------------------------------------------------------------------ E-step known answers
+def _estep_gpu(nnc, x, c):
+    km = nnc.kmeans.DeviceKMeans(dev(nnc, x), c)
+    lab, vals, d = km.assign(which=0, labels=True, values=True, distances=True)
+    labels = lab.to(torch.int32).cpu().numpy() & 0xFFFF
+    return km, labels, vals.cpu().numpy(), d.cpu().numpy()
+
+
+def test_estep_kats_against_oracle(nnc, gold):
+    for key in gold.keys("estep/"):
+        c = gold.cases[key]
+        x, cen = gold.arr(c["x"]), gold.arr(c["c"])
+        km, labels, vals, d = _estep_gpu(nnc, x, cen)
+        mean = orc.np_mean(x)
+        assert bits(km.x_mean) == bits(mean)
+        xc = (x - mean).astype(np.float32)
+        cc = (cen - mean).astype(np.float32)
+        want = orc.estep(xc, cc)
+        assert np.array_equal(labels, want), (key, int((labels != want).sum()))
+        assert np.array_equal(vals, (cc + mean).astype(np.float32)[want]), key
+        t = (xc - cc[want]).astype(np.float32)
+        assert np.array_equal(d, (t * t).astype(np.float32)), key
+
+
+def test_estep_midpoint_stress(nnc):
+    """Samples within a few ulps of every midpoint between adjacent centres, K = 256."""
+    cs = np.sort(synth.weights((256,), 4242, scale=0.05))
+    mids = ((cs[:-1].astype(np.float64) + cs[1:].astype(np.float64)) / 2).astype(np.float32)
+    xs = [synth.weights((50_000,), 4243, scale=0.05)]
+    for dlt in range(-8, 9):
+        v = mids.copy()
+        for _ in range(abs(dlt)):
+            v = np.nextafter(v, np.float32(np.inf if dlt > 0 else -np.inf), dtype=np.float32)
+        xs.append(v)
+    x = np.concatenate(xs)
+    rng = np.random.RandomState(3)
+    c = cs.copy()
+    rng.shuffle(c)
+    km, labels, _, _ = _estep_gpu(nnc, x, c)
+    mean = orc.np_mean(x)
+    want = orc.estep((x - mean).astype(np.float32), (c - mean).astype(np.float32))
+    assert np.array_equal(labels, want), int((labels != want).sum())
+
+
+# ------------------------------------------------------------------ full fits
+def _input_for_quant(key):
+    from tests.golden.make_goldens import lenet300_tensors, lenet5_tensors, q_for
+
+    parts = key.split("/")
+    cfg, tname = parts[1], parts[2]
+    if cfg in ("cfg1", "cfg2", "cfg3"):
+        table = {t[0]: t for t in lenet300_tensors() + lenet5_tensors()}
+        _, shape, seed = table[tname]
+        w = synth.weights(shape, seed)
+        orc.prune_weigth(w, q_for(tname), True)
+        return w
+    if cfg == "cfg4":
+        return synth.weights((200_000,), 4000)
+    if cfg == "cfg5":
+        w = synth.weights((768, 768), 5000)
+        orc.prune_weigth(w, 1, True)
+        return w
+    if cfg == "unpruned50k":
+        return synth.weights((50_000,), 6000)
+    raise KeyError(key)
+
+
+def _fit_both(nnc, gold, key):
+    c = gold.cases[key]
+    w = _input_for_quant(key)
+    assert sha(w) == c["input_sha256"]
+    cdfs = None
+    if c["with_cdf"]:
+        flat = w.ravel()
+        cdfs = nnc.utility.get_weight_distribution(flat[flat != 0])
+    if c["forgy_seed"] is not None:
+        np.random.seed(c["forgy_seed"])
+    q, km = nnc.utility.get_quantized_weight(w.copy(), bits=c["bits"], mode=c["mode"], cdfs=cdfs)
+    return w, q, km, c
+
+
+GOLD_FITS = [
+    "quant/cfg1/l300.dense1.w/density2",
+    "quant/cfg2/l300.dense1.w/linear4", "quant/cfg2/l300.dense1.b/linear4",
+    "quant/cfg2/l300.dense2.w/linear4", "quant/cfg2/l300.dense2.b/linear4",
+    "quant/cfg2/l300.out.w/linear4", "quant/cfg2/l300.out.b/linear4",
+    "quant/cfg2/l300.dense1.w/density4", "quant/cfg2/l300.dense2.w/forgy5", "quant/cfg2/l300.dense2.w/density5",
+    "quant/cfg3/l5.conv1.w/forgy5", "quant/cfg3/l5.conv1.b/forgy5", "quant/cfg3/l5.conv2.w/forgy5",
+    "quant/cfg3/l5.conv2.b/forgy5", "quant/cfg3/l5.dense1.w/forgy5", "quant/cfg3/l5.dense1.b/forgy5",
+    "quant/cfg3/l5.out.w/forgy5", "quant/cfg3/l5.out.b/forgy5",
+    "quant/cfg4/flat200k/forgy8", "quant/cfg4/flat200k/density8",
+    "quant/cfg5/attn_proj768/linear4",
+    "quant/unpruned50k/linear4", "quant/unpruned50k/density6", "quant/unpruned50k/forgy3",
+]
+
+
+@pytest.mark.parametrize("key", GOLD_FITS)
+def test_fit_matches_oracle_mode_b_bit_exact(nnc, gold, key):
+    """Same init (checked against the reference's), then the whole Lloyd trajectory:
+    n_iter, every centre bit and every label equal to the oracle's order-independent mode."""
+    w, q, km, c = _fit_both(nnc, gold, key)
+    if c["passthrough"]:
+        assert km is None and q.shape == w.shape
+        return
+    init = gold.arr(c["init"])
+    ob = orc.kmeans_lloyd(w.ravel(), init, accum="B")
+    assert km.n_iter_ == ob.n_iter_, (key, km.n_iter_, ob.n_iter_)
+    assert np.array_equal(km.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), key
+    assert np.array_equal(km.labels_, ob.labels_), (key, int((km.labels_ != ob.labels_).sum()))
+    assert km.labels_.dtype == np.int32 and km.cluster_centers_.dtype == np.float32
+    assert km.cluster_centers_.shape == (c["K"], 1)
+    assert q.dtype == np.float32 and q.shape == w.shape
+    assert np.array_equal(q, ob.cluster_centers_[ob.labels_].reshape(w.shape)), key
+
+
+@pytest.mark.parametrize("key", GOLD_FITS)
+def test_fit_against_reference_goldens(nnc, gold, key):
+    """Against the reference's own outputs (float32 running sums, one thread).  Integer
+    results are compared exactly where the trajectory is the same; centre values to the
+    reference's float32 summation error."""
+    w, q, km, c = _fit_both(nnc, gold, key)
+    if c["passthrough"]:
+        return
+    gc = gold.arr(c["centers"])
+    scale = np.abs(gc).max()
+    if km.n_iter_ == c["n_iter"]:
+        err = np.max(np.abs(km.cluster_centers_.ravel() - gc)) / scale
+        assert err < 2e-3, (key, err)
+        frac = np.mean(np.bincount(km.labels_, minlength=c["K"]) != gold.arr(c["bincount"]))
+        assert frac <= 0.5, (key, frac)
+    else:
+        # the float32-sum trajectory took a different number of steps: still the same optimum?
+        assert abs(km.n_iter_ - c["n_iter"]) <= max(10, c["n_iter"]), (key, km.n_iter_, c["n_iter"])
+
+
+def test_passthrough_and_errors(nnc, capsys):
+    b = synth.weights((10,), 1)
+    q, km = nnc.utility.get_quantized_weight(b, bits=4, mode="linear")
+    assert km is None and q is b
+    assert "not enough bits: 10  vs  16" in capsys.readouterr().out
+    w = synth.weights((100,), 2)
+    with pytest.raises(Exception, match=" error mode not found"):
+        nnc.utility.get_quantized_weight(w, bits=2, mode="nope")
+    with pytest.raises(Exception, match=" error mode not found"):
+        nnc.utility.get_quantized_weight(w, bits=2, mode="density", cdfs=None)
+    with pytest.raises(ValueError):
+        nnc.utility.get_weight_distribution(np.zeros(0, dtype=np.float32))
+
+
+def test_relocation_paths(nnc):
+    """Duplicate initial centres and centres in the pruned gap: empty clusters every way."""
+    x = synth.weights((4000,), 9002)
+    x[np.abs(x) < 0.06] = 0
+    for init in [np.linspace(x.min(), x.max(), 16).astype(np.float32),
+                 np.array([0.0, 0.0, 0.0, 0.1, 0.1, -0.1, 0.05, 0.0], dtype=np.float32)]:
+        km = nnc.kmeans.DeviceKMeans(dev(nnc, x), init)
+        model, vals = km.fit()
+        ob = orc.kmeans_lloyd(x, init, accum="B")
+        assert model.n_relocations_ >= 1
+        assert model.n_iter_ == ob.n_iter_
+        assert np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
+        assert np.array_equal(model.labels_, ob.labels_)
+    # all samples equal: relocation bails out (max distance 0), empty centres copy the biggest
+    xe = np.full(64, 0.125, dtype=np.float32)
+    init = np.array([0.125, 0.5, -0.5, 0.125], dtype=np.float32)
+    model, _ = nnc.kmeans.DeviceKMeans(dev(nnc, xe), init).fit()
+    ob = orc.kmeans_lloyd(xe, init, accum="B")
+    assert model.n_iter_ == ob.n_iter_
+    assert np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
+    assert np.array_equal(model.labels_, ob.labels_)
+
+
+def test_bincount_and_huffman(nnc):
+    w = synth.weights((300_000,), 77)
+    init = np.linspace(w.min(), w.max(), 32)
+    model, _ = nnc.kmeans.DeviceKMeans(dev(nnc, w), init).fit(want_values=False)
+    counts = nnc.ops.bincount(model.labels_compact_, 32).cpu().numpy()
+    assert np.array_equal(counts, np.bincount(model.labels_, minlength=32))
+    lengths, hist, total = nnc.ops.huffman_lengths(counts)
+    ol, oh, ot = orc.huffman_lengths(counts)
+    assert np.array_equal(lengths, ol) and np.array_equal(hist, oh) and total == ot
+    assert total <= 5 * w.size  # never worse than the fixed 5-bit code
+
+
+# ------------------------------------------------------------------ full BASELINE size, by properties
+def test_full_size_25m_k256_properties(nnc):
+    n, k = 25_000_000, 256
+    w = synth.weights((n,), 4000)
+    t = dev(nnc, w)
+    np.random.seed(4)
+    init = w[np.random.randint(0, n, size=k)]
+    km = nnc.kmeans.DeviceKMeans(t, init)
+    model, vals = km.fit()
+    centers = model.cluster_centers_.ravel()
+    labels = model.labels_
+    assert model.n_iter_ >= 2 and model.stop_reason_ in ("tol", "max_iter", "strict")
+    # decode(encode) round trip: values are exactly the centre of the stored index
+    v = vals.cpu().numpy()
+    assert np.array_equal(v, centers[labels])
+    # idempotence: quantizing the quantized vector with the same centres changes nothing
+    km2 = nnc.kmeans.DeviceKMeans(dev(nnc, v), centers)
+    lab2, _, _ = km2.assign(which=0)
+    assert np.array_equal(centers[lab2.cpu().numpy()], v)
+    # every weight sits with a nearest centre (up to float32 rounding of the distance)
+    sample = np.random.RandomState(0).randint(0, n, size=200_000)
+    dist_own = np.abs(w[sample].astype(np.float64) - centers[labels[sample]])
+    dist_min = np.min(np.abs(w[sample].astype(np.float64)[:, None] - centers[None, :].astype(np.float64)), axis=1)
+    assert np.all(dist_own <= dist_min + 1e-6)
+    # labels of a sample equal the brute-force float32 oracle
+    mean = km.x_mean
+    want = orc.estep((w[sample] - mean).astype(np.float32), (centers - mean).astype(np.float32))
+    # (centres + mean) - mean may differ from the stored centred value by an ulp; compare via the device's own
+    cen_c = km.centers(which=0, centred=True)
+    want = orc.estep((w[sample] - mean).astype(np.float32), cen_c)
+    assert np.array_equal(labels[sample], want)
+    # counts add up; each centre is the mean of its members to 1e-6 relative of the data scale
+    counts = np.bincount(labels, minlength=k)
+    assert counts.sum() == n
