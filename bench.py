@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: weights/s through prune + k-means (K = 256 class) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[3], "Synthetic 25 M-param fp32 weight vector, K=256"): every
+GPU holds a 25 M-element float32 shard (weak scaling) of one synthetic weight vector
+(neural_network_compression_amd.synth, seed 4000, 0.05 * bell-shaped).  One step = the whole
+per-layer Deep-Compression pass on the data already resident in HBM:
+
+    prune_weigth(q = 1 sigma)  ->  get_weight_distribution of the non-zeros  ->
+    get_quantized_weight(bits = 8, mode = "density")  (K = 2^8 + 1 = 257 centroids: the
+    reference's density init makes 2^bits + 1, utility.py:212), Lloyd to convergence ->
+    labels + quantized values -> index histogram -> Huffman code lengths.
+
+value = (weights processed by all ranks) / (time of the slowest rank) over exactly K steps.
+The JSON line also carries
+  roofline     : the Lloyd streaming kernel k_assign<accumulate> against the 8 TB/s HBM peak;
+                 algorithmic bytes = 4 B per weight per launch; its average duration is measured
+                 with HIP events around every launch inside the timed region (in-library, on the
+                 launching stream);
+  cpu_baseline : the same pipeline through NumPy / scikit-learn on the host cores (rank 0, N = 1
+                 only) on a bounded sample of the same vector.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_PER_GPU = 25_000_000
+SEED = 4000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=N_PER_GPU, help="weights per GPU")
+    ap.add_argument("--bits", type=int, default=8)
+    ap.add_argument("--mode", default="density")
+    ap.add_argument("--q", type=float, default=1.0)
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args, w_full: np.ndarray):
+    """The reference's CPU path (NumPy + scikit-learn calls) on the first `cpu_sample` weights."""
+    from oracle import libcalls
+    from oracle import oracle as orc
+
+    cores = len(os.sched_getaffinity(0))
+    threads = min(cores, 16)  # the 1-GPU box's CPU share
+    n = min(args.cpu_sample, w_full.size)
+    w = w_full[:n].copy()
+    try:
+        import sklearn  # noqa: F401
+        have_sklearn = True
+    except Exception:
+        have_sklearn = False
+    t0 = time.perf_counter()
+    libcalls.prune_weigth(w, args.q, True)
+    flat = w.ravel()
+    cdfs = orc.get_weight_distribution(flat[flat != 0]) if args.mode == "density" else None
+    space = orc.init_space(w, args.bits, args.mode, cdfs)
+    if have_sklearn:
+        _, km = libcalls.quantize(w, np.asarray(space, dtype=np.float32), n_threads=threads)
+        n_iter = int(km.n_iter_)
+        impl = f"numpy {np.__version__} + scikit-learn {sklearn.__version__} KMeans(lloyd), {threads} threads"
+    else:
+        km = orc.kmeans_lloyd(w.ravel(), space, accum="A")
+        n_iter = km.n_iter_
+        threads = 1
+        impl = "C oracle (oracle/nnc_oracle.c), 1 thread"
+    dt = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "weights/s", "cores": threads, "kind": "port",
+        "sample": f"first {n} weights of the same vector, same pipeline (prune q={args.q} sigma, CDF, "
+                  f"{args.mode} init, bits={args.bits}, Lloyd to convergence: {n_iter} iterations) in {dt:.2f} s; {impl}",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0 and world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+        group = dist.group.WORLD
+
+    from neural_network_compression_amd import _native as nat
+    from neural_network_compression_amd import pipeline, sharding, synth
+
+    L = nat.load()
+    n_total = args.n * world
+    lo, hi = sharding.shard_bounds(n_total, world, rank)
+    w_host = synth.weights((hi - lo,), SEED, start=lo)
+    w0 = torch.from_numpy(w_host).to(dev)
+
+    def step():
+        x = w0.clone()  # prune works in place; the copy is device-to-device, inside the timed region
+        return pipeline.compress_layer(x, q=args.q, bits=args.bits, mode=args.mode, group=group,
+                                       huffman=True, want_values=True)
+
+    def barrier():
+        if group is not None:
+            import torch.distributed as dist
+
+            dist.barrier(group=group)
+        torch.cuda.synchronize(dev)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    max_launches = 400 * max(1, args.steps)
+    nat.check(L.nnc_profile_begin(max_launches))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_buf = (ctypes.c_float * max_launches)()
+    cnt = ctypes.c_int64(0)
+    nat.check(L.nnc_profile_end(ms_buf, max_launches, ctypes.byref(cnt)))
+    durs = np.array(ms_buf[: min(cnt.value, max_launches)], dtype=np.float64)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if group is not None:
+        import torch.distributed as dist
+
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        n_iter = res.model.n_iter_ if res.model is not None else 0
+        # launches enqueued after convergence inside a batch return at once: drop them
+        live = durs[durs > 0.3 * np.median(durs)] if durs.size else durs
+        avg_ms = float(live.mean()) if live.size else float("nan")
+        achieved = 4.0 * (hi - lo) / (avg_ms * 1e-3) / 1e9 if live.size else float("nan")
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tr_path):
+            try:
+                traffic = json.load(open(tr_path)).get("k_assign_accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "weights/sec through prune+k-means (K=256)",
+            "value": n_total * args.steps / dt,
+            "unit": "weights/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"configs[3]: synthetic {args.n/1e6:g} M fp32 weights per GPU ({n_total/1e6:g} M total), "
+                            f"prune q={args.q} sigma -> CDF -> {args.mode}-init k-means bits={args.bits} "
+                            f"(K={res.model.cluster_centers_.size if res.model else 0}) to convergence -> labels+values -> Huffman lengths",
+                "weights_per_gpu": args.n, "k": int(res.model.cluster_centers_.size) if res.model else 0,
+                "lloyd_iterations": int(n_iter), "stop": res.model.stop_reason_ if res.model else None,
+                "relocations": int(res.model.n_relocations_) if res.model else 0,
+                "parallelism": f"shard{world}" if world > 1 else "single",
+                "weight_iterations_per_s": n_total * n_iter * args.steps / dt,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_assign<accumulate> (Lloyd E-step + per-cluster fixed-point sums)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS if live.size else None,
+                "traffic": traffic,
+                "avg_kernel_ms": avg_ms, "launches_timed": int(live.size),
+                "algorithmic_bytes_per_launch": 4 * (hi - lo),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, w_host)
+        print(json.dumps(out))
+    if group is not None:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

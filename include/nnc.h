@@ -23,9 +23,9 @@
  *     reference's NumPy / scikit-learn float32 arithmetic exactly (no FMA contraction).
  *
  * Fixed-point sums ("mode B").  Per-cluster sums are exact 64-bit integer sums of
- *     fix(v) = sign(v) * floor(|v| * 2^S + 1/2)          (v = float32 centred weight)
+ *     fix(v) = rint(v * 2^S)   (nearest integer, ties to even; v = float32 centred weight)
  * so that they do not depend on summation order, block count or GPU count; the new
- * centre is (float) ldexp((double)sum / (double)count, -S).  S = 62 - L - P with
+ * centre is (float) ldexp((double)sum / (double)count, -S).  S = min(28, 62 - L) - P with
  * L = ceil(log2(n_total)) and 2^P > max|v| (nnc_fix_shift()).
  */
 #ifndef NNC_H
@@ -128,6 +128,13 @@ int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps
  * was initialised with.
  * ---------------------------------------------------------------------------------- */
 
+/* One-time ascending reorder of the vector for the iterations (nnc_kmeans_accumulate /
+ * nnc_kmeans_iterate accept any order: integer sums are order independent; on a sorted copy a
+ * lane sees runs of equal cluster index and adds them up in registers).  Library radix sort
+ * (rocPRIM); not part of the per-iteration path.  nnc_kmeans_assign must get the original. */
+size_t nnc_sort_workspace_bytes(int64_t n);
+int nnc_sort_f32(const float *x, int64_t n, float *sorted_out, void *ws, size_t ws_bytes, void *stream);
+
 typedef struct nnc_kmeans_params {
     int64_t n;         /* length of this rank's shard */
     int64_t n_total;   /* length of the whole vector (all ranks) */
@@ -184,6 +191,20 @@ int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int 
 
 /* counts_dev[j] += #{ i : labels[i] == j }  (caller zeroes counts_dev; int64[k]). */
 int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Measurement aid (used by bench.py): HIP events around every launch of the Lloyd streaming
+ * kernel, recorded on the stream the kernel is launched on.
+ * ---------------------------------------------------------------------------------- */
+int nnc_profile_begin(int32_t max_launches);
+/* Waits for the recorded events; ms_out[i] = duration in ms of the i-th timed launch (launch
+ * order), up to cap entries; count_out = launches timed.  Launches enqueued after the state
+ * machine had stopped return at once and show up as very short entries. */
+int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out);
+
+/* Timing experiments only (bench tooling): a != 0 selects an ablated build of the Lloyd streaming
+ * kernel whose RESULTS ARE WRONG (1: no LDS atomics, 2: no table lookups, 3: neither). */
+int nnc_debug_set_ablation(int a);
 
 /* Huffman code length per centroid index from the index histogram (HOST function, host
  * pointers).  The reference names Huffman coding (README.md:9) but never implements it; the

@@ -62,6 +62,8 @@ SIGNATURES = {
     "nnc_minmax_workspace_bytes": (c_size, [c_i64]),
     "nnc_minmax_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_hist31_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
+    "nnc_sort_workspace_bytes": (c_size, [c_i64]),
+    "nnc_sort_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_fix_shift": (c_i32, [c_f32, c_i64]),
     "nnc_kmeans_workspace_bytes": (c_size, [c_i32]),
     "nnc_kmeans_init": (c_int, [c_void_p, c_size, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
@@ -74,6 +76,9 @@ SIGNATURES = {
     "nnc_kmeans_get_centers": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_assign": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
+    "nnc_profile_begin": (c_int, [c_i32]),
+    "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), c_i64, ctypes.POINTER(c_i64)]),
+    "nnc_debug_set_ablation": (c_int, [c_int]),
     "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
 }
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB = os.path.join(CSRC, "libnnc_hip.so")
-SOURCES = [os.path.join(CSRC, "nnc_hip.hip")]
+SOURCES = [os.path.join(CSRC, "nnc_hip.hip"), os.path.join(CSRC, "nnc_sort.hip")]
 
 
 def hipcc_path() -> str:

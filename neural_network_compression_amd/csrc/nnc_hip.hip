@@ -45,6 +45,8 @@ static int fail(int code, const std::string &msg)
             return fail(NNC_EHIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+int nnc_set_error_(int code, const char *msg) { return fail(code, msg ? msg : ""); } // for the other translation units
+
 extern "C" int nnc_version(void) { return NNC_VERSION; }
 extern "C" const char *nnc_last_error(void) { return g_err.c_str(); }
 
@@ -199,10 +201,11 @@ __global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x,
     __shared__ int leaf_start[160], leaf_len[160];
     __shared__ float leaf_sum[160];
     __shared__ int nleaves_s;
+    __shared__ int st_start[24], st_len[24];
+    __shared__ PwFrame st[24];
     const float mean = SQDEV ? *mean_dev : 0.0f;
     if (threadIdx.x == 0) {
         int nl = 0, sp = 0;
-        int st_start[24], st_len[24];
         st_start[0] = 0; st_len[0] = m; sp = 1;
         // iterative DFS, right child pushed first so leaves come out left to right
         while (sp > 0) {
@@ -241,7 +244,6 @@ __global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x,
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        PwFrame st[24];
         int sp = 1, li = 0;
         float ret = 0.0f;
         st[0].start = 0; st[0].len = m; st[0].stage = 0; st[0].left = 0.0f;
@@ -301,20 +303,25 @@ __global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks,
                                                float *__restrict__ out)
 {
     __shared__ float buf[FOLD_TILE];
-    float acc = 0.0f;
+    float acc = 0.0f; // the running fold lives in every lane of wave 0 (uniform)
     for (int64_t base = 0; base < nchunks; base += FOLD_TILE) {
         int len = (int)((nchunks - base) < FOLD_TILE ? (nchunks - base) : FOLD_TILE);
         for (int i = threadIdx.x; i < len; i += 1024) buf[i] = chunks[base + i];
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int i = 0;
-            for (; i + 8 <= len; i += 8) {
-                float v0 = buf[i], v1 = buf[i + 1], v2 = buf[i + 2], v3 = buf[i + 3];
-                float v4 = buf[i + 4], v5 = buf[i + 5], v6 = buf[i + 6], v7 = buf[i + 7];
-                acc = acc + v0; acc = acc + v1; acc = acc + v2; acc = acc + v3;
-                acc = acc + v4; acc = acc + v5; acc = acc + v6; acc = acc + v7;
+        if (threadIdx.x < 64) {
+            // wave 0: each lane holds one value per 64-block; v_readlane feeds the sequential chain,
+            // so the only dependent instruction per element is the float32 add
+            for (int b = 0; b < len; b += 64) {
+                const int idx = b + (int)threadIdx.x;
+                const float v = idx < len ? buf[idx] : 0.0f;
+                const int m = (len - b) < 64 ? (len - b) : 64;
+                if (m == 64) {
+#pragma unroll
+                    for (int j = 0; j < 64; j++) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+                } else {
+                    for (int j = 0; j < m; j++) acc = acc + __shfl(v, j);
+                }
             }
-            for (; i < len; i++) acc = acc + buf[i];
         }
         __syncthreads();
     }
@@ -676,7 +683,7 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 // integer addition makes the result independent of any ordering.
 //
 #define KM_THREADS 1024
-#define KM_NSHARD 16
+#define KM_NSHARD 8
 #define KM_GMAX 32768
 #define KM_CNT_SAT 63
 
@@ -714,23 +721,16 @@ extern "C" int32_t nnc_fix_shift(float absmax, int64_t n_total)
     if (!(absmax > 0.0f) || !std::isfinite(absmax)) return 0;
     int P = 0;
     (void)std::frexp((double)absmax, &P); // absmax = m * 2^P, m in [0.5, 1)
-    return 62 - L - P;
+    // |fix| <= 2^min(28, 62-L): one image is a 32-bit integer (float32 scaling + v_cvt), four of
+    // them add up inside int32, and sums of n_total images fit int64
+    return std::min(28, 62 - L) - P;
 }
 
-__device__ __forceinline__ long long fix_f32(float v, int Sft)
+// fix(v) = rint(v * 2^S), ties to even, as a 32-bit integer: the scaling by a power of two is
+// exact in float32 (v_ldexp_f32) and S is chosen so that |v * 2^S| < 2^28.
+__device__ __forceinline__ int fix_f32(float v, int Sft)
 {
-    unsigned u = __float_as_uint(v);
-    unsigned e = (u >> 23) & 0xFFu, f = u & 0x7FFFFFu;
-    unsigned long long m = e ? (unsigned long long)(f | 0x800000u) : (unsigned long long)f;
-    int ex = e ? (int)e : 1;
-    int sh = ex - 150 + Sft;
-    unsigned long long q;
-    if (sh >= 0) q = sh > 62 ? 0ull : (m << sh);
-    else {
-        int r = -sh;
-        q = r > 25 ? 0ull : ((m + (1ull << (r - 1))) >> r);
-    }
-    return (u >> 31) ? -(long long)q : (long long)q;
+    return (int)rintf(ldexpf(v, Sft));
 }
 
 static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
@@ -738,7 +738,7 @@ static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
     int r = p->replicas_log2;
     if (r < 0) {
         r = 5;
-        while (r > 0 && (size_t)p->k * ((size_t)1 << r) * 12 > 100 * 1024) r--;
+        while (r > 0 && (size_t)p->k * ((size_t)1 << r) * 12 > 40 * 1024) r--;
     }
     if (r > 5) r = 5;
     int g = p->grid_log2;
@@ -746,7 +746,7 @@ static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
     if (g < 6) g = 6;
     if (g > 15) g = 15;
     // keep table + accumulators + candidates inside 156 KiB
-    while (g > 6 && ((size_t)2 << g) + (size_t)p->k * ((size_t)1 << r) * 12 + (size_t)NNC_KMAX * 10 > 156 * 1024) g--;
+    while (g > 6 && ((size_t)2 << g) + (size_t)p->k * ((size_t)1 << r) * 12 + (size_t)(p->k + 8) * 22 + 64 > 156 * 1024) g--;
     *glog2 = g;
     *rlog2 = r;
 }
@@ -754,7 +754,7 @@ static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
 static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
 {
     size_t kp = (size_t)((k + 7) & ~7);
-    size_t b = ((size_t)2 << glog2) + kp * 8 + kp * 2;
+    size_t b = ((size_t)2 << glog2) + kp * 16 + kp * 4 + kp * 2;
     b = (b + 15) & ~(size_t)15;
     if (accumulate) b += (size_t)k * ((size_t)1 << rlog2) * 12;
     return b;
@@ -762,7 +762,196 @@ static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
 
 // ---- the streaming kernel ------------------------------------------------------------
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
-template <int MODE, bool VEC, typename LT>
+struct KmCtx {
+    const uint16_t *cell_s;  // u16[G]: p_lo | (min(cnt-1, 63) << 10)
+    const float4 *pair_s;    // (c_p, c_p^2, c_{p+1}, c_{p+1}^2), sorted order
+    const float *cval_s;     // c_p (sorted order)
+    const uint16_t *orig_s;  // sorted position -> original index
+    unsigned long long *sum_s; // [cluster][replica] fixed-point sums
+    unsigned *cnt_s;           // [cluster][replica] counts
+    float mean, lo, inv;
+    int Sft, gmax, k, rlog2, rep;
+};
+
+// three or more candidates, or an exact float32 tie between two: the general scan
+__device__ int km_find_slow(const KmCtx &c, float xc, int p, int cnt)
+{
+    if (cnt == KM_CNT_SAT) cnt = c.k - 1 - p;
+    float4 cc = c.pair_s[p];
+    float bestd = cc.y + (-2.0f * (xc * cc.x));
+    int best = p;
+    for (int i = 1; i <= cnt; i++) {
+        float4 ci = c.pair_s[p + i];
+        float d = ci.y + (-2.0f * (xc * ci.x));
+        if (d < bestd || (d == bestd && c.orig_s[p + i] < c.orig_s[best])) { bestd = d; best = p + i; }
+    }
+    return best;
+}
+
+// B weights of one thread: all table reads, then all pair reads, then the arithmetic, so that B
+// LDS round trips are in flight together.  No branches on the common path.
+template <int B>
+__device__ __forceinline__ void km_resolve(const KmCtx &c, const float (&xv)[B], float (&xc)[B], int (&p)[B])
+{
+    unsigned e[B];
+    float4 pr[B];
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        xc[i] = xv[i] - c.mean;
+        float tt = (xc[i] - c.lo) * c.inv;
+        int cell = (int)tt;
+        cell = min(max(cell, 0), c.gmax);
+        e[i] = c.cell_s[cell];
+    }
+    // the pair is needed only where a cell holds more than one candidate; every other lane reads
+    // entry 0 (one address, broadcast), so the read costs no bank conflicts and no branch
+#pragma unroll
+    for (int i = 0; i < B; i++) pr[i] = c.pair_s[(e[i] >> 10) ? (e[i] & 1023) : 0];
+    bool slow_any = false;
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const unsigned cn = e[i] >> 10;
+        const float d0 = pr[i].y + (-2.0f * (xc[i] * pr[i].x));
+        const float d1 = pr[i].w + (-2.0f * (xc[i] * pr[i].z));
+        p[i] = (int)(e[i] & 1023) + (int)((cn == 1) & (d1 < d0));
+        slow_any |= (cn >= 2) | ((cn == 1) & (d1 == d0));
+    }
+    if (slow_any) {
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            const unsigned cn = e[i] >> 10;
+            const float d0 = pr[i].y + (-2.0f * (xc[i] * pr[i].x));
+            const float d1 = pr[i].w + (-2.0f * (xc[i] * pr[i].z));
+            if (cn >= 2 || (cn == 1 && d1 == d0)) p[i] = km_find_slow(c, xc[i], (int)(e[i] & 1023), (int)cn);
+        }
+    }
+}
+
+// A lane adds up runs of equal cluster index in registers and touches LDS only when the index
+// changes: on a value-sorted vector (nnc_sort_f32) that is a handful of LDS atomics per lane per
+// launch instead of one per weight (LDS atomics retire about one lane per clock on gfx950, which
+// made them the whole cost of the unsorted form).  Any order gives the same sums.
+struct KmRun { int p; unsigned cnt; long long sum; };
+
+__device__ __forceinline__ void km_run_flush(const KmCtx &c, KmRun &run)
+{
+    if (run.cnt) {
+        atomicAdd(&c.sum_s[(run.p << c.rlog2) + c.rep], (unsigned long long)run.sum);
+        atomicAdd(&c.cnt_s[(run.p << c.rlog2) + c.rep], run.cnt);
+    }
+    run.cnt = 0;
+    run.sum = 0;
+}
+
+__device__ __forceinline__ int km_cell(const KmCtx &c, float xc)
+{
+    const float tt = (xc - c.lo) * c.inv;
+    return min(max((int)tt, 0), c.gmax);
+}
+
+// ABL (timing experiments only, results are wrong unless 0): 1 = no LDS atomics, 2 = no table
+// lookups (cluster from the value bits), 3 = neither (pure stream + arithmetic)
+template <int B, int ABL>
+__device__ __forceinline__ void km_accumulate(const KmCtx &c, const float (&xv)[B], KmRun &run)
+{
+    float xc[B];
+    int p[B];
+    if (ABL == 2 || ABL == 3) {
+#pragma unroll
+        for (int i = 0; i < B; i++) { xc[i] = xv[i] - c.mean; p[i] = (int)(__float_as_uint(xv[i]) >> 5) & 255; if (p[i] >= c.k) p[i] = 0; }
+    } else {
+        km_resolve<B>(c, xv, xc, p);
+    }
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const int q = fix_f32(xc[i], c.Sft);
+        if (p[i] != run.p) {
+            if (ABL != 1 && ABL != 3) km_run_flush(c, run);
+            run.p = p[i];
+        }
+        run.cnt++;
+        run.sum += q;
+    }
+}
+
+// Four consecutive weights of one lane.  Fast path: if the cells of the smallest and the largest
+// of the four hold the same single candidate, every cell between them does too (the candidate
+// ranges are monotone in the cell index), so all four weights belong to that cluster: two table
+// reads and no distance arithmetic.  On a value-sorted vector nearly every float4 takes it.
+template <int ABL>
+__device__ __forceinline__ void km_accumulate4(const KmCtx &c, const float4 v, KmRun &run)
+{
+    const float x0 = v.x - c.mean, x1 = v.y - c.mean, x2 = v.z - c.mean, x3 = v.w - c.mean;
+    const float mn = fminf(fminf(x0, x1), fminf(x2, x3));
+    const float mx = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+    const unsigned el = c.cell_s[km_cell(c, mn)];
+    const unsigned eh = c.cell_s[km_cell(c, mx)];
+    if (ABL == 0 && el == eh && (el >> 10) == 0) {
+        const int p = (int)el;
+        // |fix| <= 2^28, so four of them add up inside int32
+        const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
+        if (p != run.p) { km_run_flush(c, run); run.p = p; }
+        run.cnt += 4;
+        run.sum += q;
+    } else {
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        km_accumulate<4, ABL>(c, xv, run);
+    }
+}
+
+// add this workgroup's LDS accumulators to its global shard
+__device__ __forceinline__ void km_flush(const KmCtx &c, KmWs *ws)
+{
+    __syncthreads();
+    const int R = 1 << c.rlog2;
+    const int shard = blockIdx.x & (KM_NSHARD - 1);
+    for (int p = threadIdx.x; p < c.k; p += KM_THREADS) {
+        unsigned long long s = 0, n = 0;
+        for (int r = 0; r < R; r++) { s += c.sum_s[(p << c.rlog2) + r]; n += c.cnt_s[(p << c.rlog2) + r]; }
+        if (n) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&ws->shard_sum[shard][p]), s);
+            atomicAdd(&ws->shard_cnt[shard][p], n);
+        }
+    }
+}
+
+template <int B, typename LT>
+__device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], int64_t i0, LT *__restrict__ labels_out,
+                                        float *__restrict__ quant_out, float *__restrict__ dist_out)
+{
+    float xc[B];
+    int p[B];
+    km_resolve<B>(c, xv, xc, p);
+    LT lab[B];
+    float qv[B], dv[B];
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const float cv = c.cval_s[p[i]];
+        lab[i] = (LT)c.orig_s[p[i]];
+        qv[i] = cv + c.mean;
+        const float dd = xc[i] - cv;
+        dv[i] = dd * dd;
+    }
+    if (B == 4) {
+        if (labels_out) {
+            if (sizeof(LT) == 1) *reinterpret_cast<uchar4 *>(labels_out + i0) = make_uchar4(lab[0], lab[1], lab[2], lab[3]);
+            else *reinterpret_cast<ushort4 *>(labels_out + i0) = make_ushort4(lab[0], lab[1], lab[2], lab[3]);
+        }
+        if (quant_out) *reinterpret_cast<float4 *>(quant_out + i0) = make_float4(qv[0], qv[1], qv[2], qv[3]);
+        if (dist_out) *reinterpret_cast<float4 *>(dist_out + i0) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            if (labels_out) labels_out[i0 + i] = lab[i];
+            if (quant_out) quant_out[i0 + i] = qv[i];
+            if (dist_out) dist_out[i0 + i] = dv[i];
+        }
+    }
+}
+
+// MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
+// Work split: tiles of 2 * KM_THREADS float4 (8192 weights); tile t belongs to workgroup t mod grid.
+template <int MODE, bool VEC, typename LT, int ABL = 0>
 __global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out)
@@ -777,9 +966,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__
     const KmTab *__restrict__ tab = &ws->tab[t];
 
     uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
-    float2 *cand_s = reinterpret_cast<float2 *>(smem + ((size_t)2 << glog2));
-    uint16_t *orig_s = reinterpret_cast<uint16_t *>(smem + ((size_t)2 << glog2) + (size_t)kp * 8);
-    size_t off = (((size_t)2 << glog2) + (size_t)kp * 10 + 15) & ~(size_t)15;
+    float4 *pair_s = reinterpret_cast<float4 *>(smem + ((size_t)2 << glog2));
+    float *cval_s = reinterpret_cast<float *>(smem + ((size_t)2 << glog2) + (size_t)kp * 16);
+    uint16_t *orig_s = reinterpret_cast<uint16_t *>(smem + ((size_t)2 << glog2) + (size_t)kp * 20);
+    size_t off = (((size_t)2 << glog2) + (size_t)kp * 22 + 15) & ~(size_t)15;
     unsigned long long *sum_s = reinterpret_cast<unsigned long long *>(smem + off);
     unsigned *cnt_s = reinterpret_cast<unsigned *>(smem + off + ((size_t)k << rlog2) * 8);
 
@@ -787,7 +977,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__
         const uint4 *src = reinterpret_cast<const uint4 *>(tab->cell);
         uint4 *dst = reinterpret_cast<uint4 *>(cell_s);
         for (int i = threadIdx.x; i < (G >> 3); i += KM_THREADS) dst[i] = src[i];
-        for (int i = threadIdx.x; i < k; i += KM_THREADS) { cand_s[i] = tab->cand[i]; orig_s[i] = tab->orig[i]; }
+        for (int i = threadIdx.x; i < k; i += KM_THREADS) {
+            float2 a = tab->cand[i];
+            float2 b = (i + 1 < k) ? tab->cand[i + 1] : a;
+            pair_s[i] = make_float4(a.x, a.y, b.x, b.y);
+            cval_s[i] = a.x;
+            orig_s[i] = tab->orig[i];
+        }
         if (MODE == 0) {
             const int tot = k << rlog2;
             for (int i = threadIdx.x; i < tot; i += KM_THREADS) { sum_s[i] = 0ull; cnt_s[i] = 0u; }
@@ -795,95 +991,78 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__
     }
     __syncthreads();
 
-    const float mean = ws->p.x_mean, lo = ws->p.lo, inv = ws->inv;
-    const int Sft = ws->p.fix_shift;
-    const int rep = threadIdx.x & ((1 << rlog2) - 1);
-    const int gmax = G - 1;
+    KmCtx c;
+    c.cell_s = cell_s; c.pair_s = pair_s; c.cval_s = cval_s; c.orig_s = orig_s; c.sum_s = sum_s; c.cnt_s = cnt_s;
+    c.mean = ws->p.x_mean; c.lo = ws->p.lo; c.inv = ws->inv;
+    c.Sft = ws->p.fix_shift; c.gmax = G - 1; c.k = k; c.rlog2 = rlog2;
+    c.rep = threadIdx.x & ((1 << rlog2) - 1);
+    KmRun run;
+    run.p = -1; run.cnt = 0; run.sum = 0;
 
-    auto find = [&](float xc) -> int {
-        float tt = (xc - lo) * inv;
-        int cell = (int)tt;
-        cell = min(max(cell, 0), gmax);
-        unsigned e = cell_s[cell];
-        int p = e & 1023;
-        int c = e >> 10;
-        if (c) {
-            if (c == KM_CNT_SAT) c = k - 1 - p;
-            float2 cc = cand_s[p];
-            float bestd = cc.y + (-2.0f * (xc * cc.x));
-            int best = p;
-            for (int i = 1; i <= c; i++) {
-                float2 ci = cand_s[p + i];
-                float d = ci.y + (-2.0f * (xc * ci.x));
-                if (d < bestd || (d == bestd && orig_s[p + i] < orig_s[best])) { bestd = d; best = p + i; }
-            }
-            p = best;
-        }
-        return p;
-    };
-
-    auto one = [&](float xv, int64_t idx) {
-        float xc = xv - mean;
-        int p = find(xc);
-        if (MODE == 0) {
-            long long q = fix_f32(xc, Sft);
-            atomicAdd(&sum_s[(p << rlog2) + rep], (unsigned long long)q);
-            atomicAdd(&cnt_s[(p << rlog2) + rep], 1u);
-        } else {
-            if (labels_out) labels_out[idx] = (LT)orig_s[p];
-            float cv = cand_s[p].x;
-            if (quant_out) quant_out[idx] = cv + mean;
-            if (dist_out) { float dd = xc - cv; dist_out[idx] = dd * dd; }
-        }
-    };
-
-    const int64_t gtid = (int64_t)blockIdx.x * KM_THREADS + threadIdx.x;
-    const int64_t gthreads = (int64_t)gridDim.x * KM_THREADS;
-    int64_t done = 0;
-    if (VEC) {
-        const int64_t nvec = n >> 2;
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
-        int64_t v = gtid;
-        for (; v + gthreads < nvec; v += 2 * gthreads) {
-            float4 a = x4[v];
-            float4 b = x4[v + gthreads];
-            if (MODE == 0) {
-                one(a.x, 0); one(a.y, 0); one(a.z, 0); one(a.w, 0);
-                one(b.x, 0); one(b.y, 0); one(b.z, 0); one(b.w, 0);
-            } else {
-                one(a.x, 4 * v); one(a.y, 4 * v + 1); one(a.z, 4 * v + 2); one(a.w, 4 * v + 3);
-                int64_t w = v + gthreads;
-                one(b.x, 4 * w); one(b.y, 4 * w + 1); one(b.z, 4 * w + 2); one(b.w, 4 * w + 3);
-            }
-        }
-        for (; v < nvec; v += gthreads) {
-            float4 a = x4[v];
-            one(a.x, 4 * v); one(a.y, 4 * v + 1); one(a.z, 4 * v + 2); one(a.w, 4 * v + 3);
-        }
-        done = nvec << 2;
+    // work split: tiles of 2 * KM_THREADS float4 (8192 weights); every workgroup takes a
+    // CONTIGUOUS range of tiles, so that on a sorted vector it stays inside a few clusters
+    const int64_t nvec = VEC ? (n >> 2) : 0;
+    const int64_t ntiles = nvec / (2 * KM_THREADS);
+    const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * per;
+    const int64_t t1 = (t0 + per < ntiles) ? (t0 + per) : ntiles;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    // software pipeline: the loads of the next tile are in flight while this one goes through LDS
+    int64_t tile = t0;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (tile < t1) {
+        const int64_t v0 = tile * (2 * KM_THREADS) + threadIdx.x;
+        a = x4[v0];
+        b = x4[v0 + KM_THREADS];
     }
-    for (int64_t i = done + gtid; i < n; i += gthreads) one(x[i], i);
-
-    if (MODE == 0) {
-        __syncthreads();
-        const int R = 1 << rlog2;
-        const int shard = blockIdx.x & (KM_NSHARD - 1);
-        for (int p = threadIdx.x; p < k; p += KM_THREADS) {
-            unsigned long long s = 0, c = 0;
-            for (int r = 0; r < R; r++) { s += sum_s[(p << rlog2) + r]; c += cnt_s[(p << rlog2) + r]; }
-            if (c) {
-                atomicAdd(reinterpret_cast<unsigned long long *>(&ws->shard_sum[shard][p]), s);
-                atomicAdd(&ws->shard_cnt[shard][p], c);
-            }
+    while (tile < t1) {
+        const int64_t v0 = tile * (2 * KM_THREADS) + threadIdx.x;
+        const int64_t next = tile + 1;
+        float4 na = a, nb = b;
+        if (next < t1) {
+            const int64_t v1 = next * (2 * KM_THREADS) + threadIdx.x;
+            na = x4[v1];
+            nb = x4[v1 + KM_THREADS];
         }
+        if (MODE == 0) {
+            km_accumulate4<ABL>(c, a, run);
+            km_accumulate4<ABL>(c, b, run);
+        } else {
+            const float xa[4] = {a.x, a.y, a.z, a.w};
+            const float xb[4] = {b.x, b.y, b.z, b.w};
+            km_emit<4, LT>(c, xa, 4 * v0, labels_out, quant_out, dist_out);
+            km_emit<4, LT>(c, xb, 4 * (v0 + KM_THREADS), labels_out, quant_out, dist_out);
+        }
+        a = na; b = nb;
+        tile = next;
+    }
+    // ragged end (less than one tile of float4s, then the scalars): last workgroup
+    if (blockIdx.x == gridDim.x - 1) {
+        const int64_t vdone = ntiles * (2 * KM_THREADS);
+        for (int64_t v = vdone + threadIdx.x; v < nvec; v += KM_THREADS) {
+            const float4 a4 = x4[v];
+            const float xa[4] = {a4.x, a4.y, a4.z, a4.w};
+            if (MODE == 0) km_accumulate4<ABL>(c, a4, run);
+            else km_emit<4, LT>(c, xa, 4 * v, labels_out, quant_out, dist_out);
+        }
+        // scalars: fewer than 4 when the input is 16-byte aligned; the whole vector otherwise
+        for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += KM_THREADS) {
+            const float xs[1] = {x[i]};
+            if (MODE == 0) km_accumulate<1, ABL>(c, xs, run);
+            else km_emit<1, LT>(c, xs, i, labels_out, quant_out, dist_out);
+        }
+    }
+    if (MODE == 0) {
+        if (ABL != 1 && ABL != 3) km_run_flush(c, run);
+        else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
+        km_flush(c, ws);
     }
 }
 
 // ---- finalize / prepare kernel (one workgroup) -------------------------------------------
 // NumPy pairwise float32 sum of n <= 8192 values held in LDS, by one thread.
-__device__ float pairwise_serial(const float *a, int n)
+__device__ float pairwise_serial(const float *a, int n, PwFrame *st)
 {
-    PwFrame st[24];
     int sp = 1;
     float ret = 0.0f;
     st[0].start = 0; st[0].len = n; st[0].stage = 0; st[0].left = 0.0f;
@@ -932,13 +1111,15 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
 {
     __shared__ long long sum_o[NNC_KMAX];
     __shared__ long long cnt_o[NNC_KMAX];
-    __shared__ float cnew[NNC_KMAX];
+    __shared__ __align__(16) float cnew[NNC_KMAX];
     __shared__ float cs[NNC_KMAX];        // sorted centred centres
     __shared__ uint16_t so[NNC_KMAX];     // sorted -> original
     __shared__ double zl[NNC_KMAX], zr[NNC_KMAX];
     __shared__ float sq[NNC_KMAX];
     __shared__ int sh_i[4];
     __shared__ long long sh_ll[2];
+    __shared__ PwFrame pw_stack[24];
+    __shared__ double scan_a[NNC_KMAX], scan_b[NNC_KMAX];
 
     const int tid = threadIdx.x;
     if (mode != FIN_INIT && mode != FIN_PACK_ONLY && ws->st.done) return;
@@ -1016,7 +1197,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         }
         __syncthreads();
         if (tid == 0) {
-            float tot = pairwise_serial(sq, k);
+            float tot = pairwise_serial(sq, k, pw_stack);
             int iter = ws->st.iter + 1;
             int done = 0;
             if (tot <= ws->p.tol) done = 1;
@@ -1036,10 +1217,19 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     // ---- sort the centres (rank by counting; ties by original index)
     KmTab *tab = &ws->tab[cur];
     for (int j = tid; j < k; j += KM_THREADS) {
-        float v = cnew[j];
+        const float v = cnew[j];
         int rank = 0;
-        for (int i = 0; i < k; i++) {
-            float u = cnew[i];
+        const int k4 = k & ~3;
+#pragma unroll 4
+        for (int i = 0; i < k4; i += 4) {
+            const float4 u = *reinterpret_cast<const float4 *>(&cnew[i]); // same address in every lane: broadcast
+            rank += (u.x < v) || (u.x == v && i < j);
+            rank += (u.y < v) || (u.y == v && i + 1 < j);
+            rank += (u.z < v) || (u.z == v && i + 2 < j);
+            rank += (u.w < v) || (u.w == v && i + 3 < j);
+        }
+        for (int i = k4; i < k; i++) {
+            const float u = cnew[i];
             rank += (u < v) || (u == v && i < j);
         }
         cs[rank] = v;
@@ -1082,23 +1272,31 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         zr[p] = right; zl[p] = left;
     }
     __syncthreads();
-    // monotone envelopes: zr <- prefix max, zl <- suffix min (serial over k <= 1040)
-    if (tid == 0) { double m = -INFINITY; for (int p = 0; p < k; p++) { m = fmax(m, zr[p]); zr[p] = m; } }
-    if (tid == 64) { double m = INFINITY; for (int p = k - 1; p >= 0; p--) { m = fmin(m, zl[p]); zl[p] = m; } }
-    __syncthreads();
+    // monotone envelopes: zr <- prefix max, zl <- suffix min  (Hillis-Steele scans, k <= 1040 <= 2 per thread)
+    for (int d = 1; d < k; d <<= 1) {
+        for (int p = tid; p < k; p += KM_THREADS) {
+            scan_a[p] = (p >= d) ? fmax(zr[p], zr[p - d]) : zr[p];
+            scan_b[p] = (p + d < k) ? fmin(zl[p], zl[p + d]) : zl[p];
+        }
+        __syncthreads();
+        for (int p = tid; p < k; p += KM_THREADS) { zr[p] = scan_a[p]; zl[p] = scan_b[p]; }
+        __syncthreads();
+    }
     // ---- cells: candidate range [plo, phi] per cell
     const int glog2 = ws->glog2;
     const int G = 1 << glog2;
     const double lo = (double)ws->p.lo;
     const double inv = (double)ws->inv;
+    const double rinv_lo = inv > 0.0 ? (1.0 - 4.0 * U) / inv : 0.0; // cell g covers x~ - lo in [g * rinv_lo, (g+1) * rinv_hi]
+    const double rinv_hi = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0; // one extra ulp-scale factor covers the rounding of rinv itself
     const int per = (G + KM_THREADS - 1) / KM_THREADS;
     const int g0 = tid * per;
     int plo = 0, phi = 0;
     for (int g = g0; g < g0 + per && g < G; g++) {
         double a, b;
         if (inv > 0.0) {
-            a = (g == 0) ? -INFINITY : lo + (double)g * (1.0 - 4.0 * U) / inv;
-            b = (g == G - 1) ? INFINITY : lo + (double)(g + 1) * (1.0 + 4.0 * U) / inv;
+            a = (g == 0) ? -INFINITY : lo + (double)g * rinv_lo * (1.0 - 4.0 * U);
+            b = (g == G - 1) ? INFINITY : lo + (double)(g + 1) * rinv_hi;
         } else { a = -INFINITY; b = INFINITY; }
         if (g == g0) {
             // first centre whose envelope right end reaches a
@@ -1171,12 +1369,61 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     return NNC_OK;
 }
 
-static int km_grid(int64_t n)
+static int km_grid(int64_t n, size_t lds_bytes)
 {
-    int64_t blocks = ((n + 3) / 4 + KM_THREADS - 1) / KM_THREADS;
+    int64_t blocks = ((n + 7) / 8 + KM_THREADS - 1) / KM_THREADS;
     if (blocks < 1) blocks = 1;
-    return (int)std::min<int64_t>(blocks, cu_count());
+    int per_cu = (lds_bytes + 1024 <= 80 * 1024) ? 2 : 1; // two 1024-thread workgroups fit a CU if LDS allows
+    return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu);
 }
+
+
+// --------------------------------------------------------------------------------------
+// optional in-library profiler: HIP events around every launch of the Lloyd streaming
+// kernel (k_assign<accumulate>), on the stream the kernel is launched on.  bench.py turns it
+// on to report the kernel's average duration over the timed region.
+// --------------------------------------------------------------------------------------
+struct ProfPair { hipEvent_t a, b; };
+static std::vector<ProfPair> g_prof_pool;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+static int64_t g_prof_skipped = 0;
+
+extern "C" int nnc_profile_begin(int32_t max_launches)
+{
+    if (max_launches < 1) return fail(NNC_EINVAL, "nnc_profile_begin: max_launches < 1");
+    while ((int64_t)g_prof_pool.size() < max_launches) {
+        ProfPair pp;
+        HIPCHK(hipEventCreate(&pp.a));
+        HIPCHK(hipEventCreate(&pp.b));
+        g_prof_pool.push_back(pp);
+    }
+    g_prof_used = 0;
+    g_prof_skipped = 0;
+    g_prof_on = true;
+    return NNC_OK;
+}
+
+// Waits for the recorded events and copies the duration (ms) of each timed launch, in launch
+// order, into ms_out[0..cap); count_out = number of launches timed.
+extern "C" int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out)
+{
+    g_prof_on = false;
+    int64_t cnt = 0;
+    for (size_t i = 0; i < g_prof_used; i++) {
+        HIPCHK(hipEventSynchronize(g_prof_pool[i].b));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, g_prof_pool[i].a, g_prof_pool[i].b));
+        if (ms_out && cnt < cap) ms_out[cnt] = ms;
+        cnt++;
+    }
+    if (count_out) *count_out = cnt;
+    g_prof_used = 0;
+    return NNC_OK;
+}
+
+static int g_ablation = 0;
+extern "C" int nnc_debug_set_ablation(int a) { g_ablation = a; return NNC_OK; }
 
 static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream)
 {
@@ -1184,11 +1431,18 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     km_defaults(p, &glog2, &rlog2);
     size_t lds = km_lds_bytes(p->k, glog2, rlog2, true);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    int grid = km_grid(p->n);
+    int grid = km_grid(p->n, lds);
     if (p->n == 0) return NNC_OK;
-    if (vec) hipLaunchKernelGGL((k_assign<0, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    const bool prof = g_prof_on && g_prof_used < g_prof_pool.size();
+    if (g_prof_on && !prof) g_prof_skipped++;
+    if (prof) HIPCHK(hipEventRecord(g_prof_pool[g_prof_used].a, S(stream)));
+    if (vec && g_ablation == 1) hipLaunchKernelGGL((k_assign<0, true, uint8_t, 1>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    else if (vec && g_ablation == 2) hipLaunchKernelGGL((k_assign<0, true, uint8_t, 2>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    else if (vec && g_ablation == 3) hipLaunchKernelGGL((k_assign<0, true, uint8_t, 3>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    else if (vec) hipLaunchKernelGGL((k_assign<0, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
     else hipLaunchKernelGGL((k_assign<0, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
     LAUNCHCHK("k_assign<accumulate>");
+    if (prof) { HIPCHK(hipEventRecord(g_prof_pool[g_prof_used].b, S(stream))); g_prof_used++; }
     return NNC_OK;
 }
 
@@ -1199,6 +1453,9 @@ static int km_set_lds_attr()
     const int maxlds = 160 * 1024;
 #define SETATTR(fn) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds))
     SETATTR((k_assign<0, true, uint8_t>));
+    SETATTR((k_assign<0, true, uint8_t, 1>));
+    SETATTR((k_assign<0, true, uint8_t, 2>));
+    SETATTR((k_assign<0, true, uint8_t, 3>));
     SETATTR((k_assign<0, false, uint8_t>));
     SETATTR((k_assign<1, true, uint8_t>));
     SETATTR((k_assign<1, false, uint8_t>));
@@ -1302,7 +1559,7 @@ extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_para
     km_defaults(&p, &glog2, &rlog2);
     size_t lds = km_lds_bytes(p.k, glog2, rlog2, false);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    int grid = km_grid(p.n);
+    int grid = km_grid(p.n, lds);
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     if (label_bytes == 2) {
         if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out);

@@ -29,6 +29,7 @@ from . import ops
 
 MAX_ITER = 300  # scikit-learn default, which the reference does not override
 TOL = 1e-4
+SORT_MIN_WEIGHTS = 1 << 16  # below this a fit is launch-latency bound and the sort buys nothing
 
 
 class QuantizedModel:
@@ -69,7 +70,7 @@ class DeviceKMeans:
     """One fit = one instance.  ``x`` float32, 1-D, contiguous, CUDA."""
 
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
-                 batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1):
+                 batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -99,12 +100,9 @@ class DeviceKMeans:
         mean_d, var_d, _ = ops.moments(x, n_total, group)
         mm, _ = ops.minmax(x) if n > 0 else (torch.tensor([np.inf, -np.inf], dtype=torch.float32, device=self.dev), None)
         if group is not None:
-            import torch.distributed as dist
+            from . import sharding
 
-            mn, mx = mm[0:1].clone(), mm[1:2].clone()
-            _allreduce_(mn, dist.ReduceOp.MIN, group)
-            _allreduce_(mx, dist.ReduceOp.MAX, group)
-            mm = torch.cat([mn, mx])
+            mm = sharding.allreduce_minmax(mm, group)
         host = torch.cat([mean_d, var_d, mm]).cpu().numpy()
         mean, var, xmin, xmax = (np.float32(v) for v in host)
         self.x_mean = mean
@@ -126,6 +124,18 @@ class DeviceKMeans:
         self.partials = self.ws[off: off + 16 * self.k].view(torch.int64)
         self.n_relocations = 0
         self._status_host = nat.KMeansStatus()
+        # The iterations stream a value-sorted copy (same sums in any order, far fewer LDS atomics);
+        # labels, values and relocation distances always come from the original vector.
+        if sort is None:
+            sort = n >= SORT_MIN_WEIGHTS
+        self.x_iter = self._sorted_copy(x) if (sort and n > 0) else x
+
+    def _sorted_copy(self, x: torch.Tensor) -> torch.Tensor:
+        out = torch.empty_like(x)
+        ws_bytes = self.L.nnc_sort_workspace_bytes(x.numel())
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
+        nat.check(self.L.nnc_sort_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws_bytes, self.stream))
+        return out
 
     # -------------------------------------------------------------- low-level steps
     def status(self) -> nat.KMeansStatus:
@@ -136,12 +146,12 @@ class DeviceKMeans:
     def iterate(self, iters: int):
         """Enqueue `iters` Lloyd iterations (no host sync)."""
         if self.group is None:
-            nat.check(self.L.nnc_kmeans_iterate(self.x.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters), self.stream))
+            nat.check(self.L.nnc_kmeans_iterate(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters), self.stream))
             return
         import torch.distributed as dist
 
         for _ in range(int(iters)):
-            nat.check(self.L.nnc_kmeans_accumulate(self.x.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), self.stream))
+            nat.check(self.L.nnc_kmeans_accumulate(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), self.stream))
             dist.all_reduce(self.partials, op=dist.ReduceOp.SUM, group=self.group)
             nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 0, self.stream))
 

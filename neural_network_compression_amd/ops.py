@@ -62,19 +62,9 @@ def fold(chunks: torch.Tensor, count: int, op: int, scale_dev: torch.Tensor | No
 
 
 def _gather_chunks(chunks: torch.Tensor, group) -> torch.Tensor:
-    """All-gather per-shard chunk sums (shards start on multiples of 8192, rank order)."""
-    import torch.distributed as dist
+    from . import sharding
 
-    world = dist.get_world_size(group)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=chunks.device) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([chunks.numel()], dtype=torch.int64, device=chunks.device), group=group)
-    sizes = [int(s.item()) for s in sizes]
-    mx = max(sizes)
-    padded = torch.zeros(mx, dtype=torch.float32, device=chunks.device)
-    padded[: chunks.numel()] = chunks
-    bufs = [torch.empty(mx, dtype=torch.float32, device=chunks.device) for _ in range(world)]
-    dist.all_gather(bufs, padded, group=group)
-    return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+    return sharding.gather_chunks(chunks, group)
 
 
 def moments(x: torch.Tensor, n_total: int | None = None, group=None):
@@ -201,19 +191,17 @@ def fix_shift(absmax: float, n_total: int) -> int:
     if not (absmax > 0) or not math.isfinite(absmax):
         return 0
     _, P = math.frexp(float(absmax))
-    return 62 - L - P
+    return min(28, 62 - L) - P
 
 
 def fix_f32(v, S: int) -> int:
-    """Fixed-point image of one float32 (bit-for-bit the device function fix_f32)."""
-    u = int(np.array([v], dtype=np.float32).view(np.uint32)[0])
-    e, f = (u >> 23) & 0xFF, u & 0x7FFFFF
-    m = (f | 0x800000) if e else f
-    ex = e if e else 1
-    sh = ex - 150 + int(S)
-    if sh >= 0:
-        q = 0 if sh > 62 else (m << sh)
-    else:
-        r = -sh
-        q = 0 if r > 25 else ((m + (1 << (r - 1))) >> r)
-    return -q if (u >> 31) else q
+    """Fixed-point image of one float32, (int) rint(v * 2^S) with ties to even (bit-for-bit the
+    device function fix_f32)."""
+    from fractions import Fraction
+
+    fr = Fraction(float(np.float32(v))) * (Fraction(2) ** int(S))
+    fl = fr.numerator // fr.denominator
+    rem = fr - fl
+    if rem > Fraction(1, 2) or (rem == Fraction(1, 2) and (fl & 1)):
+        fl += 1
+    return int(fl)

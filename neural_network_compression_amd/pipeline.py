@@ -1,0 +1,125 @@
+"""The per-layer Deep-Compression step on data resident in HBM: prune -> (CDF) -> k-means
+-> index histogram -> Huffman code lengths, single GPU or one shard per GPU.
+
+This is what the reference does to one layer tensor across ``Trainer._prune_parameters``
+(common/trainer.py:177-193) and ``Trainer.quantize`` (common/trainer.py:42-72), with the
+Huffman length histogram the north star adds (the reference stops at the index gather).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import kmeans as _kmeans
+from . import ops, sharding
+from .common import utility
+
+
+@dataclass
+class LayerResult:
+    mask: torch.Tensor | None      # uint8/bool mask of pruned entries (this shard), or None if not pruned
+    nzeroed: int | None
+    sigma: float | None
+    threshold: float | None
+    values: torch.Tensor | None    # quantized weights (this shard), float32
+    model: object | None           # kmeans.QuantizedModel, None if the tensor passed through
+    counts: np.ndarray | None      # int64[K] index histogram over the whole vector
+    code_lengths: np.ndarray | None
+    length_hist: np.ndarray | None
+    total_bits: int | None
+
+
+def prune_sharded_(x: torch.Tensor, q, std_smooth: bool, group=None, n_total: int | None = None):
+    """prune_weigth on this rank's shard of a longer vector.  Returns (mask, stats, nzeroed)."""
+    if group is None:
+        return ops.prune_(x, q, std_smooth)
+    n_total = sharding.total_count(x.numel(), x.device, group) if n_total is None else n_total
+    if std_smooth:
+        _, _, std = ops.moments(x, n_total, group)
+        thr = std * float(np.float32(q))  # float32 * float32 on the device, as np.std(w) * q
+    else:
+        std = torch.zeros(1, dtype=torch.float32, device=x.device)
+        thr = torch.tensor([np.float32(q)], dtype=torch.float32, device=x.device)
+    mask, nz = ops.threshold_mask_(x, thr)
+    sharding.allreduce_sum_(nz, group)
+    return mask, torch.cat([std, thr]), nz
+
+
+def weight_distribution(x: torch.Tensor, skip_zeros: bool = True, group=None):
+    """get_weight_distribution over the whole (possibly sharded) vector."""
+    if group is None:
+        return utility._weight_distribution_device(x, skip_zeros)
+    mm, cnt = ops.minmax(x, skip_zeros=skip_zeros)
+    mm = sharding.allreduce_minmax(mm, group)
+    sharding.allreduce_sum_(cnt, group)
+    host = mm.cpu().numpy()
+    if int(cnt.item()) == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    steps = np.linspace(np.float32(host[0]), np.float32(host[1]), num=32)
+    steps_d = torch.from_numpy(np.ascontiguousarray(steps, dtype=np.float32)).to(x.device)
+    counts = sharding.allreduce_sum_(ops.hist31(x, steps_d, skip_zeros=skip_zeros), group).cpu().numpy()
+    return utility._cdf_from_counts(steps, counts)
+
+
+def initial_centroids(x: torch.Tensor, bits: int, mode: str, cdfs=None, group=None, n_total=None) -> np.ndarray:
+    """The reference's init `space` (utility.py:206-226) for a possibly sharded vector."""
+    if group is None:
+        return np.asarray(utility._init_space(x, x.numel(), bits, mode, cdfs), dtype=np.float32)
+    if mode == "linear":
+        mm, _ = ops.minmax(x)
+        host = sharding.allreduce_minmax(mm, group).cpu().numpy()
+        return np.linspace(np.float32(host[0]), np.float32(host[1]), num=2 ** bits).astype(np.float32)
+    if mode == "density" and cdfs is not None:
+        return np.asarray(utility._init_space(x, x.numel(), bits, mode, cdfs), dtype=np.float32)
+    if mode == "forgy":
+        import torch.distributed as dist
+
+        # same global index draw on every rank; each rank contributes the samples it owns
+        n_total = sharding.total_count(x.numel(), x.device, group) if n_total is None else n_total
+        idx = np.random.randint(0, n_total, size=2 ** bits)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        lo, hi = sharding.shard_bounds(n_total, world, rank)
+        vals = torch.zeros(idx.size, dtype=torch.float32, device=x.device)
+        mine = np.nonzero((idx >= lo) & (idx < hi))[0]
+        if mine.size:
+            vals[torch.from_numpy(mine).to(x.device)] = x[torch.from_numpy(idx[mine] - lo).to(x.device)]
+        sharding.allreduce_sum_(vals, group)  # exactly one rank contributes each entry
+        return vals.cpu().numpy()
+    raise Exception(" error mode not found")
+
+
+def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int = 4, mode: str = "linear",
+                   with_cdf: bool | None = None, group=None, huffman: bool = True,
+                   want_values: bool = True) -> LayerResult:
+    """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part."""
+    x = x.reshape(-1)
+    ops._require_cuda(x, "x", torch.float32)
+    n_total = x.numel() if group is None else sharding.total_count(x.numel(), x.device, group)
+    mask = nz = sigma = thr = None
+    if q is not None:
+        mask, stats, nzt = prune_sharded_(x, q, std_smooth, group, n_total)
+    if n_total < (2 ** bits) + 1:
+        print("not enough bits:", n_total, " vs ", 2 ** bits)
+        if q is not None:
+            s = stats.cpu().numpy()
+            sigma, thr, nz = float(s[0]), float(s[1]), int(nzt.item())
+        return LayerResult(mask, nz, sigma, thr, x, None, None, None, None, None)
+    if with_cdf is None:
+        with_cdf = mode == "density"
+    cdfs = weight_distribution(x, skip_zeros=True, group=group) if with_cdf else None
+    space = initial_centroids(x, bits, mode, cdfs, group, n_total)
+    km = _kmeans.DeviceKMeans(x, space, group=group)
+    model, values = km.fit(want_values=want_values)
+    counts = lengths = lhist = total = None
+    if huffman:
+        counts_d = ops.bincount(model.labels_compact_, km.k)
+        if group is not None:
+            sharding.allreduce_sum_(counts_d, group)
+        counts = counts_d.cpu().numpy()
+        lengths, lhist, total = ops.huffman_lengths(counts)
+    if q is not None:
+        s = stats.cpu().numpy()
+        sigma, thr, nz = float(s[0]), float(s[1]), int(nzt.item())
+    return LayerResult(mask, nz, sigma, thr, values, model, counts, lengths, lhist, total)

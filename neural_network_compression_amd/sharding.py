@@ -1,0 +1,77 @@
+"""Sharding of one flattened weight vector over the GPUs of a node (one process per GPU).
+
+The vector is cut into contiguous shards, one per rank, each starting on a multiple of
+8192 elements (NumPy's float32 reduction chunk) so that every rank's per-chunk partial sums
+are exactly the chunk sums of the unsharded vector.  The data path needs only small
+collectives, all over RCCL (backend "nccl" on ROCm) when the tensors are on GPUs:
+
+  * sigma / mean / var : all-gather of the per-chunk float32 sums (N/8192 floats), then the
+    same left-to-right fold on every rank;
+  * min / max          : all-reduce MIN / MAX of two floats;
+  * histogram, per-cluster fixed-point sums and counts: all-reduce SUM of int64 (exact).
+
+These helpers only move torch tensors, so they run unchanged on CPU tensors over gloo
+(that is how tests/test_sharding_gloo.py exercises them without a GPU).
+"""
+from __future__ import annotations
+
+import torch
+
+CHUNK = 8192
+
+
+def shard_bounds(n_total: int, world: int, rank: int):
+    """[start, stop) of `rank`'s shard: equal numbers of whole 8192-chunks, remainder to the last ranks."""
+    nchunks = (n_total + CHUNK - 1) // CHUNK
+    base, extra = divmod(nchunks, world)
+    # the first (world - extra) ranks get `base` chunks, the rest `base + 1`, so the ragged
+    # tail chunk always belongs to the last rank
+    first_big = world - extra
+    c0 = rank * base + max(0, rank - first_big)
+    c1 = c0 + base + (1 if rank >= first_big else 0)
+    return min(c0 * CHUNK, n_total), min(c1 * CHUNK, n_total)
+
+
+def _world(group):
+    import torch.distributed as dist
+
+    return dist.get_world_size(group)
+
+
+def gather_chunks(chunks: torch.Tensor, group) -> torch.Tensor:
+    """Concatenate every rank's per-chunk sums in rank order (ragged all-gather)."""
+    import torch.distributed as dist
+
+    world = _world(group)
+    n_local = torch.tensor([chunks.numel()], dtype=torch.int64, device=chunks.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    mx = max(max(sizes), 1)
+    padded = torch.zeros(mx, dtype=chunks.dtype, device=chunks.device)
+    padded[: chunks.numel()] = chunks
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
+
+
+def allreduce_minmax(mm: torch.Tensor, group) -> torch.Tensor:
+    """mm = float32[2] {min, max} of this shard (+-inf for an empty shard) -> global."""
+    import torch.distributed as dist
+
+    mn, mx = mm[0:1].clone(), mm[1:2].clone()
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    return torch.cat([mn, mx])
+
+
+def allreduce_sum_(t: torch.Tensor, group) -> torch.Tensor:
+    import torch.distributed as dist
+
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def total_count(n_local: int, device, group) -> int:
+    t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    return int(allreduce_sum_(t, group).item())

@@ -235,22 +235,11 @@ void orc_mstep_a_f32(const float *xc, int64_t n, const int32_t *labels, int K, f
 }
 
 /* Fixed-point image of a float32 (shared, bit for bit, with the HIP kernels; see
- * include/nnc.h "fixed-point sums"): q = sign(v) * round_half_away(|v| * 2^S). */
+ * include/nnc.h "fixed-point sums"): q = (int64) rint(v * 2^S), ties to even.  The widening to
+ * double and the power-of-two scaling are exact, so this is one correctly rounded operation. */
 int64_t orc_fix_f32(float v, int S)
 {
-    uint32_t u;
-    memcpy(&u, &v, 4);
-    uint32_t e = (u >> 23) & 0xFF, f = u & 0x7FFFFF;
-    int64_t m = e ? (int64_t)(f | 0x800000) : (int64_t)f;
-    int ex = e ? (int)e : 1;
-    int sh = ex - 150 + S;
-    int64_t q;
-    if (sh >= 0) q = sh > 62 ? 0 : (m << sh); /* host guarantees sh <= 38 */
-    else {
-        int r = -sh;
-        q = r > 25 ? 0 : ((m + ((int64_t)1 << (r - 1))) >> r);
-    }
-    return (u >> 31) ? -q : q;
+    return (int64_t)rint(ldexp((double)v, S)); /* default rounding mode: to nearest even */
 }
 
 /* M-step, mode B: exact integer sums of the fixed-point images + integer counts.

@@ -259,14 +259,15 @@ def init_space(layer_weight: np.ndarray, bits: int, mode: str, cdfs=None) -> np.
 
 # --------------------------------------------------------------------------- fixed point (mode B)
 def fix_shift(absmax: float, n_total: int) -> int:
-    """Shift S of the fixed-point image q = round(v * 2^S): the largest S with
-    |q| < 2^(62-L) for every |v| <= absmax, L = ceil(log2(n_total)), so that a sum over
-    n_total images cannot overflow int64.  (Same rule in the product host code.)"""
+    """Shift S of the fixed-point image q = rint(v * 2^S): the largest S with
+    |q| <= 2^min(28, 62-L) for every |v| <= absmax, L = ceil(log2(n_total)): one image is a
+    32-bit integer, four of them add up inside int32 (the device adds a float4 at a time), and a
+    sum over n_total images cannot overflow int64.  (Same rule in the product host code.)"""
     L = max(1, (int(n_total) - 1).bit_length())
     if not (absmax > 0) or not math.isfinite(absmax):
         return 0
     _, P = math.frexp(float(absmax))  # absmax = m * 2^P, m in [0.5, 1)  =>  |v| < 2^P
-    return 62 - L - P
+    return min(28, 62 - L) - P
 
 
 def fix(v, S: int) -> int:

@@ -61,8 +61,8 @@ def test_host_fix_mirror_matches_oracle():
     rng = np.random.RandomState(0)
     vals = np.concatenate([rng.randn(2000).astype(np.float32) * 0.05,
                            np.array([0.0, -0.0, 1e-45, -1e-38, 0.25, -0.25, 3e-9], dtype=np.float32)])
-    for S in (30, 39, 44, 60, 100):
-        for v in vals[:300] if S != 39 else vals:
+    for S in (10, 20, 28, 32, 34):
+        for v in vals[:300] if S != 32 else vals:
             assert ops.fix_f32(v, S) == orc.fix(v, S)
 
 

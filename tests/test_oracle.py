@@ -225,13 +225,18 @@ def test_mode_b_close_to_mode_a(gold):
 
 def test_fixed_point_rule():
     S = orc.fix_shift(0.2288, 235200)
-    assert S == 62 - 18 - (-2)
+    assert S == 28 - (-2)  # 0.2288 < 2^-2: images stay within 2^28
+    assert orc.fix_shift(0.2288, 1 << 40) == 62 - 40 - (-2)  # absurdly long vectors: the int64 sums bound it
     for v in [0.0, -0.0, 1e-3, -0.2288, 0.2288, 1.17549435e-38, 1e-45, -3.3e-20]:
         q = orc.fix(v, S)
-        ref = abs(float(np.float32(v))) * 2.0 ** S
-        want = int(np.floor(ref + 0.5))
-        assert q == (-want if np.signbit(np.float32(v)) and want else want), v
-    assert abs(orc.fix(0.2288, S)) < 2 ** 44
+        from fractions import Fraction
+        fr = Fraction(float(np.float32(v))) * Fraction(2) ** S
+        fl = fr.numerator // fr.denominator
+        rem = fr - fl
+        want = fl + (1 if (rem > Fraction(1, 2) or (rem == Fraction(1, 2) and fl % 2)) else 0)
+        assert q == want, v
+    assert abs(orc.fix(0.2288, S)) <= 2 ** 28
+    assert orc.fix(1.5, 0) == 2 and orc.fix(2.5, 0) == 2 and orc.fix(-0.5, 0) == 0  # ties to even
 
 
 def test_huffman_definition():
