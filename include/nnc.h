@@ -205,6 +205,11 @@ int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out);
 /* Timing experiments only (bench tooling): a != 0 selects an ablated build of the Lloyd streaming
  * kernel whose RESULTS ARE WRONG (1: no LDS atomics, 2: no table lookups, 3: neither). */
 int nnc_debug_set_ablation(int a);
+/* Diagnostic: if buf_dev != NULL every workgroup of the Lloyd streaming kernel stores four 100 MHz
+ * timestamps {start, loop start, loop end, end} at buf_dev[4*blockIdx]. */
+int nnc_debug_set_trace(unsigned long long *buf_dev);
+/* Diagnostic: out_dev[2b] = shader clock in GHz seen by workgroup b over a spin loop, out_dev[2b+1] = its length in us. */
+int nnc_debug_clock(int blocks, int iters, float *out_dev, void *stream);
 
 /* Huffman code length per centroid index from the index histogram (HOST function, host
  * pointers).  The reference names Huffman coding (README.md:9) but never implements it; the

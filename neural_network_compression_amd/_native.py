@@ -79,6 +79,8 @@ SIGNATURES = {
     "nnc_profile_begin": (c_int, [c_i32]),
     "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), c_i64, ctypes.POINTER(c_i64)]),
     "nnc_debug_set_ablation": (c_int, [c_int]),
+    "nnc_debug_set_trace": (c_int, [c_void_p]),
+    "nnc_debug_clock": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
 }
 

@@ -686,6 +686,9 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 #define KM_NSHARD 8
 #define KM_GMAX 32768
 #define KM_CNT_SAT 63
+#ifndef KM_RING
+#define KM_RING 4 // float4 loads kept in flight per thread
+#endif
 
 struct KmTab {
     float2 cand[NNC_KMAX];   // sorted: (c~, fl(c~*c~))
@@ -737,7 +740,10 @@ static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
 {
     int r = p->replicas_log2;
     if (r < 0) {
-        r = 5;
+        // LDS accumulator replicas: with run accumulation on a sorted vector LDS atomics are rare,
+        // so a few replicas suffice; small K (few clusters, long equal-index runs broken only by
+        // unsorted small tensors) gets the full 32
+        r = p->k <= 64 ? 5 : 2;
         while (r > 0 && (size_t)p->k * ((size_t)1 << r) * 12 > 40 * 1024) r--;
     }
     if (r > 5) r = 5;
@@ -762,6 +768,8 @@ static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
 
 // ---- the streaming kernel ------------------------------------------------------------
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
+__device__ unsigned long long *g_km_trace = nullptr; // diagnostic: per-workgroup {t_start, t_loop, t_epilogue, t_end} in 100 MHz ticks
+
 struct KmCtx {
     const uint16_t *cell_s;  // u16[G]: p_lo | (min(cnt-1, 63) << 10)
     const float4 *pair_s;    // (c_p, c_p^2, c_{p+1}, c_{p+1}^2), sorted order
@@ -952,18 +960,37 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
 // Work split: tiles of 2 * KM_THREADS float4 (8192 weights); tile t belongs to workgroup t mod grid.
 template <int MODE, bool VEC, typename LT, int ABL = 0>
-__global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
+__global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     if (MODE == 0 && (ws->st.done | ws->st.paused)) return;
+    unsigned long long *trace = (MODE == 0) ? g_km_trace : nullptr;
+    unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
+    if (trace) tr0 = __builtin_amdgcn_s_memrealtime();
     const int k = ws->p.k;
     const int glog2 = ws->glog2, rlog2 = ws->rlog2;
     const int G = 1 << glog2;
     const int kp = (k + 7) & ~7;
     const int t = ws->cur ^ (MODE == 1 ? (which & 1) : 0);
     const KmTab *__restrict__ tab = &ws->tab[t];
+
+    // work split: steps of KM_THREADS float4 (4096 weights); every workgroup takes a CONTIGUOUS
+    // range of steps, so that on a sorted vector it stays inside a few clusters.  The first loads
+    // go out before the tables are staged, so that HBM latency overlaps the prologue.
+    const int64_t nvec = VEC ? (n >> 2) : 0;
+    const int64_t nsteps = nvec / KM_THREADS;
+    const int64_t per = (nsteps + gridDim.x - 1) / gridDim.x;
+    const int64_t s0 = (int64_t)blockIdx.x * per;
+    const int64_t s1 = (s0 + per < nsteps) ? (s0 + per) : nsteps;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const float4 *base = x4 + threadIdx.x;
+    const int64_t last = s1 - 1;
+    auto ld = [&](int64_t st) -> float4 { return st <= last ? base[st * KM_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f); };
+    float4 r[KM_RING];
+#pragma unroll
+    for (int j = 0; j < KM_RING; j++) r[j] = ld(s0 + j);
 
     uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
     float4 *pair_s = reinterpret_cast<float4 *>(smem + ((size_t)2 << glog2));
@@ -998,47 +1025,28 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__
     c.rep = threadIdx.x & ((1 << rlog2) - 1);
     KmRun run;
     run.p = -1; run.cnt = 0; run.sum = 0;
+    if (trace) tr1 = __builtin_amdgcn_s_memrealtime();
 
-    // work split: tiles of 2 * KM_THREADS float4 (8192 weights); every workgroup takes a
-    // CONTIGUOUS range of tiles, so that on a sorted vector it stays inside a few clusters
-    const int64_t nvec = VEC ? (n >> 2) : 0;
-    const int64_t ntiles = nvec / (2 * KM_THREADS);
-    const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * per;
-    const int64_t t1 = (t0 + per < ntiles) ? (t0 + per) : ntiles;
-    const float4 *x4 = reinterpret_cast<const float4 *>(x);
-    // software pipeline: the loads of the next tile are in flight while this one goes through LDS
-    int64_t tile = t0;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (tile < t1) {
-        const int64_t v0 = tile * (2 * KM_THREADS) + threadIdx.x;
-        a = x4[v0];
-        b = x4[v0 + KM_THREADS];
-    }
-    while (tile < t1) {
-        const int64_t v0 = tile * (2 * KM_THREADS) + threadIdx.x;
-        const int64_t next = tile + 1;
-        float4 na = a, nb = b;
-        if (next < t1) {
-            const int64_t v1 = next * (2 * KM_THREADS) + threadIdx.x;
-            na = x4[v1];
-            nb = x4[v1 + KM_THREADS];
+    if (s0 < s1) {
+        for (int64_t st = s0; st < s1; st += KM_RING) {
+#pragma unroll
+            for (int j = 0; j < KM_RING; j++) {
+                const int64_t cur = st + j;
+                const float4 v = r[j];
+                r[j] = ld(cur + KM_RING);
+                if (cur < s1) {
+                    if (MODE == 0) km_accumulate4<ABL>(c, v, run);
+                    else {
+                        const float xa[4] = {v.x, v.y, v.z, v.w};
+                        km_emit<4, LT>(c, xa, 4 * (cur * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out);
+                    }
+                }
+            }
         }
-        if (MODE == 0) {
-            km_accumulate4<ABL>(c, a, run);
-            km_accumulate4<ABL>(c, b, run);
-        } else {
-            const float xa[4] = {a.x, a.y, a.z, a.w};
-            const float xb[4] = {b.x, b.y, b.z, b.w};
-            km_emit<4, LT>(c, xa, 4 * v0, labels_out, quant_out, dist_out);
-            km_emit<4, LT>(c, xb, 4 * (v0 + KM_THREADS), labels_out, quant_out, dist_out);
-        }
-        a = na; b = nb;
-        tile = next;
     }
     // ragged end (less than one tile of float4s, then the scalars): last workgroup
     if (blockIdx.x == gridDim.x - 1) {
-        const int64_t vdone = ntiles * (2 * KM_THREADS);
+        const int64_t vdone = nsteps * KM_THREADS;
         for (int64_t v = vdone + threadIdx.x; v < nvec; v += KM_THREADS) {
             const float4 a4 = x4[v];
             const float xa[4] = {a4.x, a4.y, a4.z, a4.w};
@@ -1052,10 +1060,15 @@ __global__ __launch_bounds__(KM_THREADS) void k_assign(const float *__restrict__
             else km_emit<1, LT>(c, xs, i, labels_out, quant_out, dist_out);
         }
     }
+    if (trace) tr2 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0) {
         if (ABL != 1 && ABL != 3) km_run_flush(c, run);
         else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
         km_flush(c, ws);
+    }
+    if (trace && threadIdx.x == 0) {
+        trace[4 * blockIdx.x + 0] = tr0; trace[4 * blockIdx.x + 1] = tr1;
+        trace[4 * blockIdx.x + 2] = tr2; trace[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -1419,6 +1432,35 @@ extern "C" int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out)
     }
     if (count_out) *count_out = cnt;
     g_prof_used = 0;
+    return NNC_OK;
+}
+
+// diagnostic: shader clock = d(s_memtime) / d(s_memrealtime) * 100 MHz over a VALU spin loop
+__global__ void k_debug_clock(int iters, float *out)
+{
+    float a = threadIdx.x * 1e-3f, b = 1.0001f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; i++) { a = a * b + 0.5f; b = b * 0.99999f + 1e-6f; }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (float)((double)(t1 - t0) / (double)(r1 - r0) * 0.1); // GHz
+        out[2 * blockIdx.x + 1] = (float)((double)(r1 - r0) * 0.01);              // us
+    }
+    if (a + b == 123.456f) out[0] = a;
+}
+
+extern "C" int nnc_debug_set_trace(unsigned long long *buf_dev)
+{
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_km_trace), &buf_dev, sizeof(buf_dev)));
+    return NNC_OK;
+}
+
+extern "C" int nnc_debug_clock(int blocks, int iters, float *out_dev, void *stream)
+{
+    hipLaunchKernelGGL(k_debug_clock, dim3(blocks), dim3(256), 0, S(stream), iters, out_dev);
+    LAUNCHCHK("k_debug_clock");
     return NNC_OK;
 }
 

@@ -60,5 +60,30 @@ nat.check(L.nnc_profile_end(buf, a.iters + 8, ctypes.byref(cnt)))
 d = np.array(buf[: cnt.value])
 print(f"  k_assign<accumulate>: {cnt.value} launches, median {np.median(d)*1e3:.1f} us, min {d.min()*1e3:.1f} us -> "
       f"{4 * a.n / (np.median(d) * 1e-3) / 1e9:.0f} GB/s = {4 * a.n / (np.median(d) * 1e-3) / 8e12 * 100:.1f} % of 8 TB/s")
+tr = torch.zeros(4 * 1024, dtype=torch.int64, device=dev)
+nat.check(L.nnc_debug_set_trace(tr.data_ptr()))
+km.iterate(1)
+torch.cuda.synchronize()
+nat.check(L.nnc_debug_set_trace(0))
+t4 = tr.cpu().numpy().reshape(-1, 4)
+t4 = t4[t4[:, 0] > 0]
+base = t4[:, 0].min()
+rel = (t4 - base) * 0.01
+print(f"  trace: {len(t4)} workgroups; start min/med/max {rel[:,0].min():.1f}/{np.median(rel[:,0]):.1f}/{rel[:,0].max():.1f} us; "
+      f"prologue med {np.median(rel[:,1]-rel[:,0]):.1f} us; loop med {np.median(rel[:,2]-rel[:,1]):.1f} max {(rel[:,2]-rel[:,1]).max():.1f} us; "
+      f"epilogue med {np.median(rel[:,3]-rel[:,2]):.1f} us; end med/max {np.median(rel[:,3]):.1f}/{rel[:,3].max():.1f} us")
+dur = rel[:, 3] - rel[:, 0]
+for x8 in range(8):
+    sel = np.arange(len(rel)) % 8 == x8
+    print(f"    blocks = {x8} mod 8: start med {np.median(rel[sel,0]):.1f}  dur med {np.median(dur[sel]):.1f} max {dur[sel].max():.1f}  end max {rel[sel,3].max():.1f}")
+order = np.argsort(rel[:, 3])[-8:]
+print("    latest workgroups:", [(int(i), round(float(rel[i,0]),1), round(float(rel[i,1]-rel[i,0]),1), round(float(rel[i,2]-rel[i,1]),1), round(float(rel[i,3]-rel[i,2]),1)) for i in order])
+clk = torch.zeros(2 * 256, device=dev)
+km.iterate(5)
+nat.check(L.nnc_debug_clock(256, 20000, clk.data_ptr(), km.stream))
+km.iterate(5)
+torch.cuda.synchronize()
+cc = clk.cpu().numpy().reshape(-1, 2)
+print(f"  shader clock right after Lloyd kernels: median {np.median(cc[:,0]):.2f} GHz (spin {np.median(cc[:,1]):.0f} us)")
 print(f"n={a.n} k={a.k} pruned={a.pruned} iters={st.iter} done={st.done} paused={st.paused} "
       f"{dt / a.iters * 1e6:.1f} us/iter (kernel+finalize, host-inclusive) -> {4 * a.n / (dt / a.iters) / 1e9:.0f} GB/s algorithmic")
