@@ -189,81 +189,15 @@ __global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x,
     }
 }
 
-// The ragged last chunk (m < 8192 elements): thread 0 walks the split tree to list the leaves,
-// 8 lanes per leaf sum them, thread 0 walks the tree again to merge.
+// The ragged last chunk (m < 8192 elements): the generic workgroup-parallel pairwise sum.
 struct PwFrame { int start, len, stage; float left; };
+struct PwHeap;
+template <typename F> __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp);
 
 template <bool SQDEV>
 __global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x, int m,
                                                     const float *__restrict__ mean_dev,
-                                                    float *__restrict__ out)
-{
-    __shared__ int leaf_start[160], leaf_len[160];
-    __shared__ float leaf_sum[160];
-    __shared__ int nleaves_s;
-    __shared__ int st_start[24], st_len[24];
-    __shared__ PwFrame st[24];
-    const float mean = SQDEV ? *mean_dev : 0.0f;
-    if (threadIdx.x == 0) {
-        int nl = 0, sp = 0;
-        st_start[0] = 0; st_len[0] = m; sp = 1;
-        // iterative DFS, right child pushed first so leaves come out left to right
-        while (sp > 0) {
-            sp--;
-            int s0 = st_start[sp], l0 = st_len[sp];
-            if (l0 <= LEAF) { leaf_start[nl] = s0; leaf_len[nl] = l0; nl++; }
-            else {
-                int n2 = l0 / 2; n2 -= n2 % 8;
-                st_start[sp] = s0 + n2; st_len[sp] = l0 - n2; sp++;
-                st_start[sp] = s0; st_len[sp] = n2; sp++;
-            }
-        }
-        nleaves_s = nl;
-    }
-    __syncthreads();
-    const int nl = nleaves_s;
-    const int j = threadIdx.x & 7;
-    for (int leaf = threadIdx.x >> 3; leaf < nl; leaf += 32) { // uniform per 8-lane group
-        const float *a = x + leaf_start[leaf];
-        const int len = leaf_len[leaf];
-        float res;
-        if (len < 8) {
-            res = 0.0f;
-            for (int i = 0; i < len; i++) res += xform1<SQDEV>(a[i], mean);
-        } else {
-            float r = xform1<SQDEV>(a[j], mean);
-            const int lim = len - (len % 8);
-            for (int i = 8; i < lim; i += 8) r += xform1<SQDEV>(a[i + j], mean);
-            r = r + __shfl_xor(r, 1);
-            r = r + __shfl_xor(r, 2);
-            r = r + __shfl_xor(r, 4);
-            res = r;
-            for (int i = lim; i < len; i++) res += xform1<SQDEV>(a[i], mean);
-        }
-        if (j == 0) leaf_sum[leaf] = res;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int sp = 1, li = 0;
-        float ret = 0.0f;
-        st[0].start = 0; st[0].len = m; st[0].stage = 0; st[0].left = 0.0f;
-        while (sp > 0) {
-            PwFrame &f = st[sp - 1];
-            if (f.len <= LEAF) { ret = leaf_sum[li++]; sp--; continue; }
-            int n2 = f.len / 2; n2 -= n2 % 8;
-            if (f.stage == 0) {
-                f.stage = 1;
-                st[sp].start = f.start; st[sp].len = n2; st[sp].stage = 0; sp++;
-            } else if (f.stage == 1) {
-                f.left = ret; f.stage = 2;
-                st[sp].start = f.start + n2; st[sp].len = f.len - n2; st[sp].stage = 0; sp++;
-            } else {
-                ret = f.left + ret; sp--;
-            }
-        }
-        *out = ret;
-    }
-}
+                                                    float *__restrict__ out);
 
 extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const float *mean_dev,
                                   float *chunk_out, void *stream)
@@ -768,6 +702,7 @@ static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
 
 // ---- the streaming kernel ------------------------------------------------------------
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
+__device__ unsigned long long *g_fin_trace = nullptr; // diagnostic: phase timestamps of k_finalize (thread 0)
 __device__ unsigned long long *g_km_trace = nullptr; // diagnostic: per-workgroup {t_start, t_loop, t_epilogue, t_end} in 100 MHz ticks
 
 struct KmCtx {
@@ -1072,49 +1007,79 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     }
 }
 
-// ---- finalize / prepare kernel (one workgroup) -------------------------------------------
-// NumPy pairwise float32 sum of n <= 8192 values held in LDS, by one thread.
-__device__ float pairwise_serial(const float *a, int n, PwFrame *st)
+
+// NumPy's pairwise float32 sum of n <= 8192 values by a whole workgroup (>= 256 threads).  The
+// split tree (n/2 rounded down to a multiple of 8, leaves of <= 128) is laid out as a binary
+// heap in LDS (node i -> children 2i, 2i+1; depth <= 7), leaves are summed by 8 lanes each, and
+// the tree is folded level by level.  F(i) returns element i.  All threads get the result.
+struct PwHeap { int start[256]; int len[256]; float val[256]; };
+
+template <typename F>
+__device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 {
-    int sp = 1;
-    float ret = 0.0f;
-    st[0].start = 0; st[0].len = n; st[0].stage = 0; st[0].left = 0.0f;
-    while (sp > 0) {
-        PwFrame &f = st[sp - 1];
-        if (f.len <= LEAF) {
-            const float *b = a + f.start;
-            int len = f.len;
-            float res;
-            if (len < 8) {
-                res = 0.0f;
-                for (int i = 0; i < len; i++) res += b[i];
-            } else {
-                float r0 = b[0], r1 = b[1], r2 = b[2], r3 = b[3], r4 = b[4], r5 = b[5], r6 = b[6], r7 = b[7];
-                int lim = len - (len % 8), i;
-                for (i = 8; i < lim; i += 8) {
-                    r0 += b[i]; r1 += b[i + 1]; r2 += b[i + 2]; r3 += b[i + 3];
-                    r4 += b[i + 4]; r5 += b[i + 5]; r6 += b[i + 6]; r7 += b[i + 7];
-                }
-                res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-                for (; i < len; i++) res += b[i];
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    for (int i = tid; i < 256; i += nthr) { hp->start[i] = 0; hp->len[i] = 0; hp->val[i] = 0.0f; }
+    __syncthreads();
+    if (tid == 0) { hp->start[1] = 0; hp->len[1] = n; }
+    __syncthreads();
+    for (int lev = 0; lev < 7; lev++) {
+        const int i = (1 << lev) + tid;
+        if (tid < (1 << lev)) {
+            const int l = hp->len[i];
+            if (l > LEAF) {
+                int n2 = l / 2; n2 -= n2 % 8;
+                hp->start[2 * i] = hp->start[i]; hp->len[2 * i] = n2;
+                hp->start[2 * i + 1] = hp->start[i] + n2; hp->len[2 * i + 1] = l - n2;
             }
-            ret = res; sp--;
-            continue;
         }
-        int n2 = f.len / 2; n2 -= n2 % 8;
-        if (f.stage == 0) {
-            f.stage = 1;
-            st[sp].start = f.start; st[sp].len = n2; st[sp].stage = 0; sp++;
-        } else if (f.stage == 1) {
-            f.left = ret; f.stage = 2;
-            st[sp].start = f.start + n2; st[sp].len = f.len - n2; st[sp].stage = 0; sp++;
-        } else {
-            ret = f.left + ret; sp--;
+        __syncthreads();
+    }
+    // leaves: 8 lanes per leaf (a group of 8 lanes stays together in the loop)
+    const int j = tid & 7;
+    for (int node = 1 + (tid >> 3); node < 256; node += (nthr >> 3)) {
+        const int l = hp->len[node];
+        if (l > 0 && l <= LEAF) {
+            const int st = hp->start[node];
+            float res;
+            if (l < 8) {
+                res = 0.0f;
+                for (int i = 0; i < l; i++) res += elem(st + i);
+            } else {
+                float r = elem(st + j);
+                const int lim = l - (l % 8);
+                for (int i = 8; i < lim; i += 8) r += elem(st + i + j);
+                r = r + __shfl_xor(r, 1);
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                res = r;
+                for (int i = lim; i < l; i++) res += elem(st + i);
+            }
+            if (j == 0) hp->val[node] = res;
         }
     }
-    return ret;
+    __syncthreads();
+    for (int lev = 6; lev >= 0; lev--) {
+        const int i = (1 << lev) + tid;
+        if (tid < (1 << lev) && hp->len[i] > LEAF) hp->val[i] = hp->val[2 * i] + hp->val[2 * i + 1];
+        __syncthreads();
+    }
+    return hp->val[1];
 }
 
+template <bool SQDEV>
+__global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x, int m,
+                                                    const float *__restrict__ mean_dev,
+                                                    float *__restrict__ out)
+{
+    __shared__ PwHeap heap;
+    const float mean = SQDEV ? *mean_dev : 0.0f;
+    const float r = block_pairwise_sum([&](int i) { return xform1<SQDEV>(x[i], mean); }, m, &heap);
+    if (threadIdx.x == 0) *out = r;
+}
+template __global__ void k_chunk_tail<true>(const float *, int, const float *, float *);
+template __global__ void k_chunk_tail<false>(const float *, int, const float *, float *);
+
+// ---- finalize / prepare kernel (one workgroup) -------------------------------------------
 #define FIN_INIT 0          // build the table for the initial centres
 #define FIN_FROM_SHARDS 1   // single GPU: reduce shards -> partials -> finalize
 #define FIN_FROM_PARTIALS 2 // multi GPU / resume: partials already hold the global sums
@@ -1129,12 +1094,15 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     __shared__ uint16_t so[NNC_KMAX];     // sorted -> original
     __shared__ double zl[NNC_KMAX], zr[NNC_KMAX];
     __shared__ float sq[NNC_KMAX];
-    __shared__ int sh_i[4];
-    __shared__ long long sh_ll[2];
-    __shared__ PwFrame pw_stack[24];
-    __shared__ double scan_a[NNC_KMAX], scan_b[NNC_KMAX];
+    __shared__ unsigned long long sh_key;
+    __shared__ PwHeap heap;
+    __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
+    __shared__ double wave_a[KM_THREADS / 64], wave_b[KM_THREADS / 64];
 
     const int tid = threadIdx.x;
+    unsigned long long *ftr = g_fin_trace;
+#define FSTAMP(i) do { if (ftr && tid == 0) ftr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    FSTAMP(0);
     if (mode != FIN_INIT && mode != FIN_PACK_ONLY && ws->st.done) return;
     if (mode == FIN_FROM_SHARDS && ws->st.paused) return;
     if (mode == FIN_PACK_ONLY && (ws->st.done | ws->st.paused)) {
@@ -1167,39 +1135,39 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         for (int j = tid; j < k; j += KM_THREADS) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
     __syncthreads();
+    FSTAMP(1);
 
     if (mode != FIN_INIT) {
-        // ---- empty clusters?
-        if (tid == 0) { sh_i[0] = 0; sh_i[1] = 0; sh_ll[0] = -1; }
-        __syncthreads();
+        // ---- empty clusters?  (one barrier-with-count)
         int my_empty = 0;
         for (int j = tid; j < k; j += KM_THREADS) my_empty += (cnt_o[j] == 0);
-        if (my_empty) atomicAdd(&sh_i[0], my_empty);
-        __syncthreads();
-        const int n_empty = sh_i[0];
+        if (tid == 0) sh_key = 0ull;
+        const int n_empty = __syncthreads_count(my_empty);
         if (n_empty > 0 && !resume) {
-            if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = n_empty; }
+            int tot_empty = 0;
+            if (tid == 0) {
+                for (int j = 0; j < k; j++) tot_empty += (cnt_o[j] == 0); // rare path, exact count
+                ws->st.paused = 1; ws->st.n_empty = tot_empty;
+            }
             return;
         }
-        // ---- _average_centers: first index of the largest count, then in index order
-        for (int j = tid; j < k; j += KM_THREADS) atomicMax(&sh_ll[0], cnt_o[j]);
-        __syncthreads();
-        if (tid == 0) sh_i[1] = k;
-        __syncthreads();
-        const long long maxc = sh_ll[0];
-        for (int j = tid; j < k; j += KM_THREADS) if (cnt_o[j] == maxc) atomicMin(&sh_i[1], j);
-        __syncthreads();
-        const int amax = sh_i[1];
+        // ---- _average_centers: first index of the largest count (key = count, then lowest index)
+        for (int j = tid; j < k; j += KM_THREADS)
+            atomicMax(&sh_key, ((unsigned long long)cnt_o[j] << 11) | (unsigned long long)(2047 - j));
         const int Sft = ws->p.fix_shift;
         for (int j = tid; j < k; j += KM_THREADS)
             if (cnt_o[j] > 0) cnew[j] = (float)ldexp((double)sum_o[j] / (double)cnt_o[j], -Sft);
         __syncthreads();
-        for (int j = tid; j < k; j += KM_THREADS)
-            if (cnt_o[j] <= 0) {
-                // sklearn copies centers[argmax] as it stands: averaged if argmax < j, raw sum otherwise
-                cnew[j] = (amax < j) ? cnew[amax] : (float)ldexp((double)sum_o[amax], -Sft);
-            }
-        __syncthreads();
+        if (n_empty > 0) { // only after a relocation that bailed out (all samples on their centres)
+            const int amax = 2047 - (int)(sh_key & 2047ull);
+            for (int j = tid; j < k; j += KM_THREADS)
+                if (cnt_o[j] <= 0) {
+                    // sklearn copies centers[argmax] as it stands: averaged if argmax < j, raw sum otherwise
+                    cnew[j] = (amax < j) ? cnew[amax] : (float)ldexp((double)sum_o[amax], -Sft);
+                }
+            __syncthreads();
+        }
+        FSTAMP(2);
         // ---- _center_shift and the tolerance test
         const float *cold = ws->c[cur];
         for (int j = tid; j < k; j += KM_THREADS) {
@@ -1209,8 +1177,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             sq[j] = sft * sft;
         }
         __syncthreads();
+        const float tot = block_pairwise_sum([&](int i) { return sq[i]; }, k, &heap);
         if (tid == 0) {
-            float tot = pairwise_serial(sq, k, pw_stack);
             int iter = ws->st.iter + 1;
             int done = 0;
             if (tot <= ws->p.tol) done = 1;
@@ -1227,26 +1195,29 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         __syncthreads();
     }
 
+    FSTAMP(3);
     // ---- sort the centres (rank by counting; ties by original index)
     KmTab *tab = &ws->tab[cur];
-    for (int j = tid; j < k; j += KM_THREADS) {
-        const float v = cnew[j];
-        int rank = 0;
-        const int k4 = k & ~3;
-#pragma unroll 4
-        for (int i = 0; i < k4; i += 4) {
-            const float4 u = *reinterpret_cast<const float4 *>(&cnew[i]); // same address in every lane: broadcast
-            rank += (u.x < v) || (u.x == v && i < j);
-            rank += (u.y < v) || (u.y == v && i + 1 < j);
-            rank += (u.z < v) || (u.z == v && i + 2 < j);
-            rank += (u.w < v) || (u.w == v && i + 3 < j);
+    {
+        // rank by counting; PARTS lanes share one element and split the comparisons
+        int parts = 1;
+        while (parts < 64 && k * parts * 2 <= KM_THREADS) parts <<= 1;
+        const int per_part = (k + parts - 1) / parts;
+        for (int t = tid; t < ((k * parts + KM_THREADS - 1) / KM_THREADS) * KM_THREADS; t += KM_THREADS) {
+            const int j = t / parts, part = t % parts;
+            int rank = 0;
+            float v = 0.0f;
+            if (j < k) {
+                v = cnew[j];
+                const int i0 = part * per_part, i1 = min(k, i0 + per_part);
+                for (int i = i0; i < i1; i++) {
+                    const float u = cnew[i];
+                    rank += (u < v) || (u == v && i < j);
+                }
+            }
+            for (int off = 1; off < parts; off <<= 1) rank += __shfl_xor(rank, off);
+            if (j < k && part == 0) { cs[rank] = v; so[rank] = (uint16_t)j; }
         }
-        for (int i = k4; i < k; i++) {
-            const float u = cnew[i];
-            rank += (u < v) || (u == v && i < j);
-        }
-        cs[rank] = v;
-        so[rank] = (uint16_t)j;
     }
     __syncthreads();
     for (int p = tid; p < k; p += KM_THREADS) {
@@ -1254,6 +1225,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         tab->cand[p] = make_float2(v, v * v);
         tab->orig[p] = so[p];
     }
+    FSTAMP(4);
     // ---- zone of every centre: the x-interval on which it can be the float32 arg-min
     const double U = 5.9604644775390625e-08; // 2^-24
     const double xb = fmax(fabs((double)ws->p.lo), fabs((double)ws->p.hi));
@@ -1285,51 +1257,104 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         zr[p] = right; zl[p] = left;
     }
     __syncthreads();
-    // monotone envelopes: zr <- prefix max, zl <- suffix min  (Hillis-Steele scans, k <= 1040 <= 2 per thread)
-    for (int d = 1; d < k; d <<= 1) {
-        for (int p = tid; p < k; p += KM_THREADS) {
-            scan_a[p] = (p >= d) ? fmax(zr[p], zr[p - d]) : zr[p];
-            scan_b[p] = (p + d < k) ? fmin(zl[p], zl[p + d]) : zl[p];
+    FSTAMP(5);
+    // monotone envelopes: zr <- prefix max, zl <- suffix min.  One element per thread, k <= 1040
+    // needs two rounds of 1024; wave scan by shuffles, then the wave totals through LDS.
+    {
+        const int rounds = (k + KM_THREADS - 1) / KM_THREADS;
+        double carry_a = -INFINITY;
+        for (int rd = 0; rd < rounds; rd++) {
+            const int p = rd * KM_THREADS + tid;
+            double a = (p < k) ? zr[p] : -INFINITY;
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_up(a, off);
+                if ((tid & 63) >= off) a = fmax(a, o);
+            }
+            if ((tid & 63) == 63) wave_a[tid >> 6] = a;
+            __syncthreads();
+            double pre = carry_a;
+            for (int w = 0; w < (tid >> 6); w++) pre = fmax(pre, wave_a[w]);
+            a = fmax(a, pre);
+            if (p < k) zr[p] = a;
+            double tot = carry_a;
+            for (int w = 0; w < KM_THREADS / 64; w++) tot = fmax(tot, wave_a[w]);
+            carry_a = tot;
+            __syncthreads();
         }
-        __syncthreads();
-        for (int p = tid; p < k; p += KM_THREADS) { zr[p] = scan_a[p]; zl[p] = scan_b[p]; }
-        __syncthreads();
+        double carry_b = INFINITY;
+        for (int rd = rounds - 1; rd >= 0; rd--) {
+            const int p = rd * KM_THREADS + tid;
+            double b = (p < k) ? zl[p] : INFINITY;
+            for (int off = 1; off < 64; off <<= 1) {
+                const double o = __shfl_down(b, off);
+                if ((tid & 63) + off < 64) b = fmin(b, o);
+            }
+            if ((tid & 63) == 0) wave_b[tid >> 6] = b;
+            __syncthreads();
+            double suf = carry_b;
+            for (int w = (tid >> 6) + 1; w < KM_THREADS / 64; w++) suf = fmin(suf, wave_b[w]);
+            b = fmin(b, suf);
+            if (p < k) zl[p] = b;
+            double tot = carry_b;
+            for (int w = 0; w < KM_THREADS / 64; w++) tot = fmin(tot, wave_b[w]);
+            carry_b = tot;
+            __syncthreads();
+        }
     }
-    // ---- cells: candidate range [plo, phi] per cell
+    FSTAMP(6);
+    // ---- cells: candidate range [plo, phi] per cell.  Cell g covers x~ - lo in
+    // [g * ra, (g+1) * rb]; centre p can open cell g iff zr[p] >= lo + g*ra  <=>  g <= G_p, and can
+    // close it iff zl[p] <= lo + (g+1)*rb  <=>  g >= H_p.  G_p, H_p are rounded outwards, which
+    // only ever widens a candidate range.
     const int glog2 = ws->glog2;
     const int G = 1 << glog2;
     const double lo = (double)ws->p.lo;
     const double inv = (double)ws->inv;
-    const double rinv_lo = inv > 0.0 ? (1.0 - 4.0 * U) / inv : 0.0; // cell g covers x~ - lo in [g * rinv_lo, (g+1) * rinv_hi]
-    const double rinv_hi = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0; // one extra ulp-scale factor covers the rounding of rinv itself
+    const double ra = inv > 0.0 ? (1.0 - 4.0 * U) / inv * (1.0 - 4.0 * U) : 0.0;
+    const double rb = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0;
+    for (int p = tid; p < k; p += KM_THREADS) {
+        int gp = G - 1, hp_ = 0;
+        if (inv > 0.0) {
+            const double qa = (zr[p] - lo) / ra;  // may be +-inf
+            // largest g with g <= qa; the relative slack covers the rounding of the quotient
+            gp = (qa >= (double)(G - 1)) ? (G - 1) : (qa < 0.0 ? -1 : (int)(qa * (1.0 + 1e-12)));
+            if (gp > G - 1) gp = G - 1;
+            const double qb = ((zl[p] - lo) / rb - 1.0) * (1.0 - 1e-12);
+            // smallest g with g >= qb
+            if (qb <= 0.0) hp_ = 0;
+            else if (qb >= (double)G) hp_ = G;
+            else { hp_ = (int)qb; if ((double)hp_ < qb) hp_++; }
+        }
+        gcell[p] = gp; hcell[p] = hp_;
+    }
+    __syncthreads();
+    // first and last cells are open-ended: everything below lo / above hi is clamped into them
     const int per = (G + KM_THREADS - 1) / KM_THREADS;
     const int g0 = tid * per;
-    int plo = 0, phi = 0;
-    for (int g = g0; g < g0 + per && g < G; g++) {
-        double a, b;
-        if (inv > 0.0) {
-            a = (g == 0) ? -INFINITY : lo + (double)g * rinv_lo * (1.0 - 4.0 * U);
-            b = (g == G - 1) ? INFINITY : lo + (double)(g + 1) * rinv_hi;
-        } else { a = -INFINITY; b = INFINITY; }
-        if (g == g0) {
-            // first centre whose envelope right end reaches a
-            int l = 0, h = k - 1;
-            while (l < h) { int m = (l + h) >> 1; if (zr[m] >= a) h = m; else l = m + 1; }
-            plo = l;
-            // last centre whose envelope left end is <= b
-            l = 0; h = k - 1;
-            while (l < h) { int m = (l + h + 1) >> 1; if (zl[m] <= b) l = m; else h = m - 1; }
-            phi = l;
-        } else {
-            while (plo < k - 1 && !(zr[plo] >= a)) plo++;
-            while (phi < k - 1 && zl[phi + 1] <= b) phi++;
+    if (g0 < G) {
+        // plo(g) = first p with G_p >= g ; phi(g) = last p with H_p <= g  (both monotone in g)
+        int l = 0, h = k - 1;
+        while (l < h) { int m = (l + h) >> 1; if (gcell[m] >= g0) h = m; else l = m + 1; }
+        int plo = l;
+        l = 0; h = k - 1;
+        while (l < h) { int m = (l + h + 1) >> 1; if (hcell[m] <= g0) l = m; else h = m - 1; }
+        int phi = l;
+        int gnext = gcell[plo];                            // plo stays while g <= gnext
+        int hnext = (phi + 1 < k) ? hcell[phi + 1] : G + 1; // phi advances once g >= hnext
+        for (int g = g0; g < g0 + per && g < G; g++) {
+            while (plo < k - 1 && gnext < g) { plo++; gnext = gcell[plo]; }
+            while (phi < k - 1 && hnext <= g) { phi++; hnext = (phi + 1 < k) ? hcell[phi + 1] : G + 1; }
+            int lo_p = (g == 0) ? 0 : plo;       // below lo nothing exists, but keep cell 0 / G-1 conservative
+            int hi_p = (g == G - 1) ? k - 1 : phi;
+            if (g == 0) { lo_p = 0; }
+            if (hi_p < lo_p) { lo_p = 0; hi_p = k - 1; }
+            int c = hi_p - lo_p;
+            if (c >= KM_CNT_SAT) c = KM_CNT_SAT;
+            tab->cell[g] = (uint16_t)(lo_p | (c << 10));
         }
-        int lo_p = plo, hi_p = phi;
-        if (hi_p < lo_p) { lo_p = 0; hi_p = k - 1; }
-        int c = hi_p - lo_p;
-        if (c >= KM_CNT_SAT) c = KM_CNT_SAT;
-        tab->cell[g] = (uint16_t)(lo_p | (c << 10));
     }
+    FSTAMP(7);
+#undef FSTAMP
 }
 
 static int km_check(void *ws, const nnc_kmeans_params *p, const char *who)
@@ -1454,6 +1479,8 @@ __global__ void k_debug_clock(int iters, float *out)
 extern "C" int nnc_debug_set_trace(unsigned long long *buf_dev)
 {
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_km_trace), &buf_dev, sizeof(buf_dev)));
+    unsigned long long *fin = buf_dev ? buf_dev + 4 * 1024 : nullptr; // finalize stamps live behind the 1024 workgroup records
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fin_trace), &fin, sizeof(fin)));
     return NNC_OK;
 }
 

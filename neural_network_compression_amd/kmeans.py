@@ -174,14 +174,39 @@ class DeviceKMeans:
         return out.cpu().numpy()
 
     # -------------------------------------------------------------- empty-cluster relocation
+    def _farthest(self, d: torch.Tensor, m: int, base: int):
+        """Indices (global) and squared distances of the m samples farthest from their centre, in
+        descending order of distance, equal distances by descending index.  The ordering key is
+        the 64-bit integer (float32 bits of d) << 32 | global index (d >= 0, so its bits sort
+        like its value); keys are unique, so the selection is deterministic on any device count."""
+        n = d.numel()
+        m_loc = min(m, n)
+        idx = torch.arange(base, base + n, dtype=torch.int64, device=self.dev)
+        key = (d.view(torch.int32).to(torch.int64) << 32) | idx
+        top = torch.topk(key, m_loc, largest=True, sorted=True).values if m_loc else key[:0]
+        if self.group is not None:
+            import torch.distributed as dist
+
+            world = dist.get_world_size(self.group)
+            pad = torch.full((m,), -1, dtype=torch.int64, device=self.dev)
+            pad[:m_loc] = top
+            bufs = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad, group=self.group)
+            allk = torch.cat(bufs)
+            top = torch.topk(allk, min(m, int((allk >= 0).sum().item())), largest=True, sorted=True).values
+        return top & 0xFFFFFFFF, (top >> 32).to(torch.int32).view(torch.float32)
+
     def _relocate_and_resume(self, st) -> bool:
         """scikit-learn's _relocate_empty_clusters_dense (_k_means_common.pyx:167-211) for a
         paused iteration, then resume the finalize step.  Returns True when the labels of
         this iteration equal those of the previous one (strict convergence).
 
-        The n_empty farthest samples are picked with numpy.argpartition on the host, because
-        which empty cluster receives which sample is defined by that routine's internal
-        order; the distances themselves come from the device."""
+        Distances, labels and the selection of the n_empty farthest samples are computed on the
+        device; the i-th empty cluster (ascending index) receives the i-th farthest sample.
+        scikit-learn pairs them in the order numpy.argpartition happens to leave the top of its
+        index array in -- the same SET of samples, the same pairing whenever n_empty == 1, and an
+        implementation-defined (CPU-dispatch dependent) pairing otherwise; descending distance is
+        what that order most often is, and it is the rule of the oracle's mode B."""
         n_empty = int(st.n_empty)
         lab, _, d = self.assign(which=0, labels=True, distances=True)
         strict = False
@@ -195,22 +220,35 @@ class DeviceKMeans:
                 _allreduce_(flag, dist.ReduceOp.SUM, self.group)
                 same = int(flag.item()) == 0
             strict = bool(same)
-        if self.group is None:
-            d_all, x_src, lab_src, base = d, self.x, lab, 0
-        else:
-            d_all, x_src, lab_src, base = self._gather_for_relocation(d, lab)
-        d_host = d_all.cpu().numpy()
-        far = np.argpartition(d_host, -n_empty)[: -n_empty - 1: -1]
-        if np.max(d_host) != 0:
+        base = 0
+        if self.group is not None:
+            import torch.distributed as dist
+            from . import sharding
+
+            base, _ = sharding.shard_bounds(self.n_total, dist.get_world_size(self.group), dist.get_rank(self.group))
+        far_idx, far_d = self._farthest(d, n_empty, base)
+        far_idx_h = far_idx.cpu().numpy()
+        far_d_h = far_d.cpu().numpy()
+        if far_d_h.size and far_d_h[0] != 0:  # np.max(distances) == 0: relocating is pointless
+            # value and current label of every chosen sample (owned by exactly one rank)
+            local = (far_idx >= base) & (far_idx < base + self.n)
+            xs = torch.zeros(far_idx.numel(), dtype=torch.float32, device=self.dev)
+            ls = torch.zeros(far_idx.numel(), dtype=torch.int64, device=self.dev)
+            li = (far_idx[local] - base)
+            xs[local] = self.x[li]
+            ls[local] = lab[li].to(torch.int64) & 0xFFFF
+            if self.group is not None:
+                import torch.distributed as dist
+
+                dist.all_reduce(xs, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(ls, op=dist.ReduceOp.SUM, group=self.group)
+            xs_h, ls_h = xs.cpu().numpy(), ls.cpu().numpy()
             part = self.partials.cpu().numpy().copy()
             sums, counts = part[: self.k], part[self.k:]
             empty = np.where(counts == 0)[0]
-            idx_t = torch.from_numpy(far.astype(np.int64)).to(self.dev)
-            xs = x_src[idx_t].cpu().numpy().astype(np.float32)
-            ls = lab_src[idx_t].to(torch.int32).cpu().numpy() & 0xFFFF
-            for i in range(n_empty):
-                new, old = int(empty[i]), int(ls[i])
-                v = ops.fix_f32(np.float32(xs[i] - self.x_mean), self.fix_shift)
+            for i in range(min(n_empty, far_idx_h.size)):
+                new, old = int(empty[i]), int(ls_h[i])
+                v = ops.fix_f32(np.float32(xs_h[i] - self.x_mean), self.fix_shift)
                 sums[old] -= v
                 sums[new] = v
                 counts[new] = 1
@@ -220,24 +258,6 @@ class DeviceKMeans:
         self.n_relocations += 1
         self._strict_labels = lab if strict else None
         return strict
-
-    def _gather_for_relocation(self, d, lab):
-        import torch.distributed as dist
-
-        world = dist.get_world_size(self.group)
-        sizes = [torch.zeros(1, dtype=torch.int64, device=self.dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([self.n], dtype=torch.int64, device=self.dev), group=self.group)
-        sizes = [int(s.item()) for s in sizes]
-        mx = max(sizes)
-
-        def gather(t, dtype):
-            pad = torch.zeros(mx, dtype=dtype, device=self.dev)
-            pad[: self.n] = t.to(dtype)
-            bufs = [torch.empty(mx, dtype=dtype, device=self.dev) for _ in range(world)]
-            dist.all_gather(bufs, pad, group=self.group)
-            return torch.cat([b[:s] for b, s in zip(bufs, sizes)])
-
-        return gather(d, torch.float32), gather(self.x, torch.float32), gather(lab.to(torch.int32) & 0xFFFF, torch.int32), 0
 
     # -------------------------------------------------------------- the fit loop
     def fit(self, want_values: bool = True):

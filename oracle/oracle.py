@@ -314,7 +314,13 @@ def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True):
     if n_empty:
         d = np.empty(xc.size, dtype=np.float32)
         L.orc_dist_own_f32(_p(xc, _f32p), xc.size, _p(c_old, _f32p), _p(labels, _i32p), _p(d, _f32p))
-        far = np.argpartition(d, -n_empty)[: -n_empty - 1 : -1].astype(np.int32)
+        if accum == "A":
+            # scikit-learn: whatever order numpy.argpartition leaves the top n_empty indices in
+            far = np.argpartition(d, -n_empty)[: -n_empty - 1 : -1].astype(np.int32)
+        else:
+            # mode B (the device rule): descending distance, equal distances by descending index.
+            # Same set of samples; same pairing as scikit-learn whenever n_empty == 1.
+            far = np.lexsort((np.arange(d.size), d))[::-1][:n_empty].astype(np.int32)
         if np.max(d) != 0:
             for idx in range(n_empty):
                 new, far_idx = int(empty[idx]), int(far[idx])

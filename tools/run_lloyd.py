@@ -60,12 +60,14 @@ nat.check(L.nnc_profile_end(buf, a.iters + 8, ctypes.byref(cnt)))
 d = np.array(buf[: cnt.value])
 print(f"  k_assign<accumulate>: {cnt.value} launches, median {np.median(d)*1e3:.1f} us, min {d.min()*1e3:.1f} us -> "
       f"{4 * a.n / (np.median(d) * 1e-3) / 1e9:.0f} GB/s = {4 * a.n / (np.median(d) * 1e-3) / 8e12 * 100:.1f} % of 8 TB/s")
-tr = torch.zeros(4 * 1024, dtype=torch.int64, device=dev)
+tr = torch.zeros(4 * 1024 + 16, dtype=torch.int64, device=dev)
 nat.check(L.nnc_debug_set_trace(tr.data_ptr()))
 km.iterate(1)
 torch.cuda.synchronize()
 nat.check(L.nnc_debug_set_trace(0))
-t4 = tr.cpu().numpy().reshape(-1, 4)
+fin = tr.cpu().numpy()[4 * 1024:]
+print('  k_finalize phases (us): start->reduce %.1f, ->average %.1f, ->shift+tol %.1f, ->sort %.1f, ->zones %.1f, ->scans %.1f, ->cells %.1f; total %.1f' % tuple([(fin[i+1]-fin[i])*0.01 for i in range(7)] + [(fin[7]-fin[0])*0.01]))
+t4 = tr.cpu().numpy()[: 4 * 1024].reshape(-1, 4)
 t4 = t4[t4[:, 0] > 0]
 base = t4[:, 0].min()
 rel = (t4 - base) * 0.01
