@@ -189,6 +189,29 @@ int nnc_kmeans_get_centers(void *ws, int which, int centred, float *out_dev, voi
 int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int which, void *labels_out,
                       int label_bytes, float *quant_out, float *dist_out, void *stream);
 
+/* Selection of the farthest samples for scikit-learn's empty-cluster relocation
+ * (_k_means_common.pyx:167-211: np.argpartition(distances, -n_empty)), on the device:
+ * hist4096_dev[b] = #{ i : ((bits(d[i]) >> 19) & 4095) == b } (zeroed here; d >= 0), then all samples
+ * in bins >= bin_min are written as keys (bits(d[i]) << 32 | base_index + i) to keys_dev[0..cap) in
+ * arbitrary order; count_dev = how many there were (may exceed cap: then nothing is usable). */
+int nnc_topm_hist_f32(const float *d, int64_t n, int64_t *hist4096_dev, void *stream);
+int nnc_topm_compact_f32(const float *d, int64_t n, int32_t bin_min, int64_t base_index, int64_t *keys_dev,
+                         int64_t cap, int64_t *count_dev, void *stream);
+
+/* The relocation edits themselves (_k_means_common.pyx:197-211), as additive changes to the
+ * per-cluster sums/counts: keys_sorted_dev = the selected samples' keys in descending order
+ * (nkeys of them); the i-th empty cluster of the workspace's partials takes the i-th sample.
+ * delta_dev (int64[2k], zeroed by the caller) receives the changes for the samples this rank
+ * owns (global index in [base_index, base_index + n_local)); the caller sums the ranks' deltas
+ * and adds them to nnc_kmeans_partials().  x / labels: this rank's shard and its current labels. */
+int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, const float *x,
+                        const void *labels, int label_bytes, int64_t base_index, int64_t n_local,
+                        int64_t *delta_dev, void *stream);
+/* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence
+ * test, _kmeans.py:717); nnc_kmeans_set_done_if sets done = done_code when *flag_dev != 0. */
+int nnc_labels_equal(const void *a, const void *b, int64_t n, int label_bytes, int32_t *flag_dev, void *stream);
+int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code, void *stream);
+
 /* counts_dev[j] += #{ i : labels[i] == j }  (caller zeroes counts_dev; int64[k]). */
 int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream);
 

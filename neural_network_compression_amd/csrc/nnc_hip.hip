@@ -1641,6 +1641,193 @@ extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_para
     return NNC_OK;
 }
 
+
+// ======================================================================================
+// 4b. farthest-sample selection for the empty-cluster relocation
+//
+// The n_empty samples with the largest squared distance to their own centre, out of millions:
+// (1) 4096-bin histogram of the top 12 value bits of the (non-negative) float32 distances, (2) the
+// host picks the lowest bin such that the bins from it upwards hold at least n_empty samples,
+// (3) every sample in those bins is compacted as a 64-bit key (distance bits << 32 | global
+// index) and the few survivors are sorted by the caller.  Keys are unique, so the outcome is
+// deterministic: descending distance, equal distances by descending index.
+// ======================================================================================
+__global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, int64_t n,
+                                                   unsigned long long *__restrict__ hist)
+{
+    __shared__ unsigned h[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+    __syncthreads();
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    const int64_t nvec = ((reinterpret_cast<uintptr_t>(d) & 15) == 0) ? (n >> 2) : 0;
+    const uint4 *d4 = reinterpret_cast<const uint4 *>(d);
+    // most distances are tiny and share a handful of bins: count runs of equal bins in registers
+    unsigned run_bin = 0xFFFFFFFFu, run_cnt = 0;
+#define TH1(u) do { unsigned b_ = ((u) >> 19) & 4095u; if (b_ != run_bin) { if (run_cnt) atomicAdd(&h[run_bin], run_cnt); run_bin = b_; run_cnt = 0; } run_cnt++; } while (0)
+    for (int64_t v = tid; v < nvec; v += nthreads) {
+        const uint4 a = d4[v];
+        TH1(a.x); TH1(a.y); TH1(a.z); TH1(a.w);
+    }
+    for (int64_t i = (nvec << 2) + tid; i < n; i += nthreads) { const unsigned u = __float_as_uint(d[i]); TH1(u); }
+#undef TH1
+    if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
+}
+
+__global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ d, int64_t n, unsigned bin_min,
+                                                      long long base_index, long long *__restrict__ keys,
+                                                      long long cap, unsigned long long *__restrict__ count)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = tid; i < n; i += nthreads) {
+        const unsigned u = __float_as_uint(d[i]);
+        if (((u >> 19) & 4095u) >= bin_min) {
+            const unsigned long long slot = atomicAdd(count, 1ull);
+            if ((long long)slot < cap) keys[slot] = ((long long)u << 32) | (base_index + i);
+        }
+    }
+}
+
+extern "C" int nnc_topm_hist_f32(const float *d, int64_t n, int64_t *hist4096_dev, void *stream)
+{
+    if (n < 0 || !hist4096_dev || (n > 0 && !d)) return fail(NNC_EINVAL, "nnc_topm_hist_f32: bad argument");
+    HIPCHK(hipMemsetAsync(hist4096_dev, 0, 4096 * sizeof(int64_t), S(stream)));
+    if (n == 0) return NNC_OK;
+    int grid = stream_grid((n + 3) / 4, 256, 8);
+    hipLaunchKernelGGL(k_topm_hist, dim3(grid), dim3(256), 0, S(stream), d, n, reinterpret_cast<unsigned long long *>(hist4096_dev));
+    LAUNCHCHK("k_topm_hist");
+    return NNC_OK;
+}
+
+extern "C" int nnc_topm_compact_f32(const float *d, int64_t n, int32_t bin_min, int64_t base_index, int64_t *keys_dev,
+                                    int64_t cap, int64_t *count_dev, void *stream)
+{
+    if (n < 0 || !keys_dev || !count_dev || cap <= 0 || bin_min < 0 || bin_min > 4095 || (n > 0 && !d))
+        return fail(NNC_EINVAL, "nnc_topm_compact_f32: bad argument");
+    HIPCHK(hipMemsetAsync(count_dev, 0, sizeof(int64_t), S(stream)));
+    if (n == 0) return NNC_OK;
+    int grid = stream_grid(n, 256 * 4, 8);
+    hipLaunchKernelGGL(k_topm_compact, dim3(grid), dim3(256), 0, S(stream), d, n, (unsigned)bin_min, (long long)base_index,
+                       reinterpret_cast<long long *>(keys_dev), (long long)cap, reinterpret_cast<unsigned long long *>(count_dev));
+    LAUNCHCHK("k_topm_compact");
+    return NNC_OK;
+}
+
+// apply scikit-learn's relocation (_k_means_common.pyx:197-211) as additive edits: the i-th empty
+// cluster (ascending index) takes the i-th key's sample; that sample's old cluster gives it up.
+// delta[0..k) sums, delta[k..2k) counts; only samples this rank owns are applied (the ranks'
+// deltas are summed by the caller).  Nothing happens when the largest distance is zero.
+template <typename LT>
+__global__ __launch_bounds__(KM_THREADS) void k_relocate(const KmWs *__restrict__ ws, const long long *__restrict__ keys,
+                                                         int nkeys, const float *__restrict__ x,
+                                                         const LT *__restrict__ labels, long long base, long long n_local,
+                                                         long long *__restrict__ delta)
+{
+    __shared__ int empty_id[NNC_KMAX];
+    __shared__ int wave_cnt[KM_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int k = ws->p.k;
+    // ordered list of the empty clusters
+    const int rounds = (k + KM_THREADS - 1) / KM_THREADS;
+    int carry = 0;
+    for (int rd = 0; rd < rounds; rd++) {
+        const int j = rd * KM_THREADS + tid;
+        const int e = (j < k && ws->partials[k + j] == 0) ? 1 : 0;
+        const unsigned long long bal = __ballot(e);
+        const int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if ((tid & 63) == 0) wave_cnt[tid >> 6] = __popcll(bal);
+        __syncthreads();
+        int pre = carry;
+        for (int w = 0; w < (tid >> 6); w++) pre += wave_cnt[w];
+        if (e) empty_id[pre + before] = j;
+        int tot = carry;
+        for (int w = 0; w < KM_THREADS / 64; w++) tot += wave_cnt[w];
+        carry = tot;
+        __syncthreads();
+    }
+    const int n_empty = carry;
+    const int m = n_empty < nkeys ? n_empty : nkeys;
+    if (m == 0 || (keys[0] >> 32) == 0) return;
+    const float mean = ws->p.x_mean;
+    const int Sft = ws->p.fix_shift;
+    for (int i = tid; i < m; i += KM_THREADS) {
+        const long long gidx = keys[i] & 0xFFFFFFFFll;
+        if (gidx >= base && gidx < base + n_local) {
+            const long long li = gidx - base;
+            const long long v = (long long)fix_f32(x[li] - mean, Sft);
+            const int old = (int)labels[li], nw = empty_id[i];
+            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[old]), (unsigned long long)(-v));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[nw]), (unsigned long long)v);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[k + nw]), 1ull);
+            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[k + old]), (unsigned long long)(-1ll));
+        }
+    }
+}
+
+extern "C" int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, const float *x,
+                                   const void *labels, int label_bytes, int64_t base_index, int64_t n_local,
+                                   int64_t *delta_dev, void *stream)
+{
+    if (!ws || !keys_sorted_dev || nkeys < 0 || !delta_dev || (n_local > 0 && (!x || !labels)))
+        return fail(NNC_EINVAL, "nnc_kmeans_relocate: bad argument");
+    if (label_bytes != 1 && label_bytes != 2) return fail(NNC_EINVAL, "nnc_kmeans_relocate: label_bytes must be 1 or 2");
+    if (nkeys == 0) return NNC_OK;
+    const KmWs *w = reinterpret_cast<const KmWs *>(ws);
+    if (label_bytes == 1)
+        hipLaunchKernelGGL((k_relocate<uint8_t>), dim3(1), dim3(KM_THREADS), 0, S(stream), w, reinterpret_cast<const long long *>(keys_sorted_dev), nkeys, x, reinterpret_cast<const uint8_t *>(labels), (long long)base_index, (long long)n_local, reinterpret_cast<long long *>(delta_dev));
+    else
+        hipLaunchKernelGGL((k_relocate<uint16_t>), dim3(1), dim3(KM_THREADS), 0, S(stream), w, reinterpret_cast<const long long *>(keys_sorted_dev), nkeys, x, reinterpret_cast<const uint16_t *>(labels), (long long)base_index, (long long)n_local, reinterpret_cast<long long *>(delta_dev));
+    LAUNCHCHK("k_relocate");
+    return NNC_OK;
+}
+
+// flag = 1 if the two label vectors are identical, else 0
+template <typename LT>
+__global__ __launch_bounds__(256) void k_labels_equal(const LT *__restrict__ a, const LT *__restrict__ b, int64_t n, int *flag)
+{
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    int diff = 0;
+    for (int64_t i = tid; i < n; i += nthreads) diff |= (a[i] != b[i]);
+    if (__any(diff) && (threadIdx.x & 63) == 0) *flag = 0;
+}
+__global__ void k_set_i32(int *p, int v) { *p = v; }
+__global__ void k_set_done_if(KmWs *ws, const int *flag, int code) { if (*flag) ws->st.done = code; }
+
+extern "C" int nnc_labels_equal(const void *a, const void *b, int64_t n, int label_bytes, int32_t *flag_dev, void *stream)
+{
+    if (!flag_dev || n < 0 || (n > 0 && (!a || !b))) return fail(NNC_EINVAL, "nnc_labels_equal: bad argument");
+    hipLaunchKernelGGL(k_set_i32, dim3(1), dim3(1), 0, S(stream), flag_dev, 1);
+    LAUNCHCHK("k_set_i32");
+    if (n == 0) return NNC_OK;
+    // compare 8 bytes at a time when both are aligned and the byte count allows it
+    const int64_t bytes = n * label_bytes;
+    if (((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b)) & 7) == 0 && (bytes & 7) == 0) {
+        int grid = stream_grid(bytes / 8, 256 * 4, 8);
+        hipLaunchKernelGGL((k_labels_equal<unsigned long long>), dim3(grid), dim3(256), 0, S(stream), reinterpret_cast<const unsigned long long *>(a), reinterpret_cast<const unsigned long long *>(b), bytes / 8, flag_dev);
+    } else if (label_bytes == 1) {
+        int grid = stream_grid(n, 256 * 4, 8);
+        hipLaunchKernelGGL((k_labels_equal<uint8_t>), dim3(grid), dim3(256), 0, S(stream), reinterpret_cast<const uint8_t *>(a), reinterpret_cast<const uint8_t *>(b), n, flag_dev);
+    } else {
+        int grid = stream_grid(n, 256 * 4, 8);
+        hipLaunchKernelGGL((k_labels_equal<uint16_t>), dim3(grid), dim3(256), 0, S(stream), reinterpret_cast<const uint16_t *>(a), reinterpret_cast<const uint16_t *>(b), n, flag_dev);
+    }
+    LAUNCHCHK("k_labels_equal");
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code, void *stream)
+{
+    if (!ws || !flag_dev) return fail(NNC_EINVAL, "nnc_kmeans_set_done_if: null pointer");
+    hipLaunchKernelGGL(k_set_done_if, dim3(1), dim3(1), 0, S(stream), reinterpret_cast<KmWs *>(ws), flag_dev, done_code);
+    LAUNCHCHK("k_set_done_if");
+    return NNC_OK;
+}
+
 // ======================================================================================
 // 5. Huffman code lengths (host)
 // ======================================================================================

@@ -181,9 +181,7 @@ class DeviceKMeans:
         like its value); keys are unique, so the selection is deterministic on any device count."""
         n = d.numel()
         m_loc = min(m, n)
-        idx = torch.arange(base, base + n, dtype=torch.int64, device=self.dev)
-        key = (d.view(torch.int32).to(torch.int64) << 32) | idx
-        top = torch.topk(key, m_loc, largest=True, sorted=True).values if m_loc else key[:0]
+        top = self._local_top_keys(d, m_loc, base) if m_loc else torch.empty(0, dtype=torch.int64, device=self.dev)
         if self.group is not None:
             import torch.distributed as dist
 
@@ -194,12 +192,37 @@ class DeviceKMeans:
             dist.all_gather(bufs, pad, group=self.group)
             allk = torch.cat(bufs)
             top = torch.topk(allk, min(m, int((allk >= 0).sum().item())), largest=True, sorted=True).values
-        return top & 0xFFFFFFFF, (top >> 32).to(torch.int32).view(torch.float32)
+        return top, None
 
-    def _relocate_and_resume(self, st) -> bool:
+    TOPM_CAP = 1 << 18
+
+    def _local_top_keys(self, d: torch.Tensor, m: int, base: int) -> torch.Tensor:
+        """The m largest keys (float32 bits of d) << 32 | (base + index) of this shard, descending:
+        histogram of the top value bits -> cut bin -> compaction of the few samples above the cut
+        (HIP kernels) -> sort of the survivors."""
+        n = d.numel()
+        hist = torch.empty(4096, dtype=torch.int64, device=self.dev)
+        nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, hist.data_ptr(), self.stream))
+        h = hist.cpu().numpy()
+        above = np.cumsum(h[::-1])[::-1]            # samples in bins >= b
+        ok = np.nonzero(above >= m)[0]
+        bin_min = int(ok[-1]) if ok.size else 0      # highest bin that still leaves >= m samples
+        cand = int(above[bin_min])
+        if cand <= self.TOPM_CAP:
+            keys = torch.empty(cand, dtype=torch.int64, device=self.dev)
+            cnt = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            nat.check(self.L.nnc_topm_compact_f32(d.data_ptr(), n, bin_min, int(base), keys.data_ptr(), cand, cnt.data_ptr(), self.stream))
+            return torch.sort(keys, descending=True).values[:m]
+        # a heavily populated cut bin (massive ties): general selection over all keys
+        idx = torch.arange(base, base + n, dtype=torch.int64, device=self.dev)
+        key = (d.view(torch.int32).to(torch.int64) << 32) | idx
+        return torch.topk(key, m, largest=True, sorted=True).values
+
+    def _relocate_and_resume(self, st) -> None:
         """scikit-learn's _relocate_empty_clusters_dense (_k_means_common.pyx:167-211) for a
-        paused iteration, then resume the finalize step.  Returns True when the labels of
-        this iteration equal those of the previous one (strict convergence).
+        paused iteration, then resume the finalize step; everything is enqueued on the device
+        (one small host read, the 4096-bin distance histogram).  If the labels of this iteration
+        equal those of the previous one the state is marked done = 3 (strict convergence).
 
         Distances, labels and the selection of the n_empty farthest samples are computed on the
         device; the i-th empty cluster (ascending index) receives the i-th farthest sample.
@@ -209,55 +232,36 @@ class DeviceKMeans:
         what that order most often is, and it is the rule of the oracle's mode B."""
         n_empty = int(st.n_empty)
         lab, _, d = self.assign(which=0, labels=True, distances=True)
-        strict = False
+        lb = 1 if self.k <= 256 else 2
+        flag = None
         if st.iter >= 1:
             prev, _, _ = self.assign(which=1, labels=True)
-            same = torch.equal(lab, prev)
+            flag = torch.empty(1, dtype=torch.int32, device=self.dev)
+            nat.check(self.L.nnc_labels_equal(lab.data_ptr(), prev.data_ptr(), self.n, lb, flag.data_ptr(), self.stream))
             if self.group is not None:
                 import torch.distributed as dist
 
-                flag = torch.tensor([0 if same else 1], dtype=torch.int64, device=self.dev)
-                _allreduce_(flag, dist.ReduceOp.SUM, self.group)
-                same = int(flag.item()) == 0
-            strict = bool(same)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         base = 0
         if self.group is not None:
             import torch.distributed as dist
             from . import sharding
 
             base, _ = sharding.shard_bounds(self.n_total, dist.get_world_size(self.group), dist.get_rank(self.group))
-        far_idx, far_d = self._farthest(d, n_empty, base)
-        far_idx_h = far_idx.cpu().numpy()
-        far_d_h = far_d.cpu().numpy()
-        if far_d_h.size and far_d_h[0] != 0:  # np.max(distances) == 0: relocating is pointless
-            # value and current label of every chosen sample (owned by exactly one rank)
-            local = (far_idx >= base) & (far_idx < base + self.n)
-            xs = torch.zeros(far_idx.numel(), dtype=torch.float32, device=self.dev)
-            ls = torch.zeros(far_idx.numel(), dtype=torch.int64, device=self.dev)
-            li = (far_idx[local] - base)
-            xs[local] = self.x[li]
-            ls[local] = lab[li].to(torch.int64) & 0xFFFF
-            if self.group is not None:
-                import torch.distributed as dist
+        keys, _ = self._farthest(d, n_empty, base)
+        delta = torch.zeros(2 * self.k, dtype=torch.int64, device=self.dev)
+        nat.check(self.L.nnc_kmeans_relocate(self.ws.data_ptr(), keys.data_ptr(), int(keys.numel()), self.x.data_ptr(),
+                                             lab.data_ptr(), lb, int(base), self.n, delta.data_ptr(), self.stream))
+        if self.group is not None:
+            import torch.distributed as dist
 
-                dist.all_reduce(xs, op=dist.ReduceOp.SUM, group=self.group)
-                dist.all_reduce(ls, op=dist.ReduceOp.SUM, group=self.group)
-            xs_h, ls_h = xs.cpu().numpy(), ls.cpu().numpy()
-            part = self.partials.cpu().numpy().copy()
-            sums, counts = part[: self.k], part[self.k:]
-            empty = np.where(counts == 0)[0]
-            for i in range(min(n_empty, far_idx_h.size)):
-                new, old = int(empty[i]), int(ls_h[i])
-                v = ops.fix_f32(np.float32(xs_h[i] - self.x_mean), self.fix_shift)
-                sums[old] -= v
-                sums[new] = v
-                counts[new] = 1
-                counts[old] -= 1
-            self.partials.copy_(torch.from_numpy(part).to(self.dev))
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
+        self.partials += delta
         nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 1, self.stream))
+        if flag is not None:
+            nat.check(self.L.nnc_kmeans_set_done_if(self.ws.data_ptr(), flag.data_ptr(), 3, self.stream))
         self.n_relocations += 1
-        self._strict_labels = lab if strict else None
-        return strict
+        self._reloc_labels = lab  # the labels of this iteration, kept in case it was the last (strict stop)
 
     # -------------------------------------------------------------- the fit loop
     def fit(self, want_values: bool = True):
@@ -269,13 +273,12 @@ class DeviceKMeans:
             self.iterate(batch)
             st = self.status()
             if st.paused:
-                # an empty cluster stopped the device loop inside this batch: relocate on the
-                # host, resume that iteration, then go on one iteration at a time for a while
-                strict = self._relocate_and_resume(st)
-                if strict:
-                    nat.check(self.L.nnc_kmeans_set_done(self.ws.data_ptr(), 3, self.stream))
-                    strict_labels = self._strict_labels
+                # an empty cluster stopped the device loop inside this batch: relocate, resume
+                # that iteration, then go on one iteration at a time for a while
+                self._relocate_and_resume(st)
                 st = self.status()
+                if int(st.done) == 3:
+                    strict_labels = self._reloc_labels
                 batch = 1
             else:
                 batch = min(self.batch, batch * 2)
