@@ -1,0 +1,166 @@
+"""Trainer with the reference's call surface, weights and masks resident on the GPU.
+
+Counterpart of neural_network_compression/common/trainer.py.  The compression steps are the
+hot path and run in the HIP kernels:
+
+    Trainer._prune_parameters        (trainer.py:177-193)  -> utility.prune_weigth per tensor, in place in HBM
+    Trainer._reset_pruned_parameters (trainer.py:195-206)  -> ops.apply_mask_ with the stored device masks
+    Trainer.quantize                 (trainer.py:42-72)    -> utility.get_weight_distribution (zeros skipped on
+                                                              the device) + utility.get_quantized_weight
+
+The reference round-trips every tensor through host NumPy on every batch
+(layer.get_weights()/set_weights()); here nothing leaves the device.  The gradient / Adam / accuracy
+parts (trainer.py:208-232, TensorFlow upstream) are a minimal torch loop: they are callers of the path,
+not the path.
+"""
+from __future__ import annotations
+
+import pathlib
+from abc import ABC, abstractmethod
+from typing import Dict, List, NamedTuple, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from . import utility
+
+
+class LeNetDataset(NamedTuple):
+    input_data: np.ndarray
+    output_data: np.ndarray
+
+
+def _batches(x: torch.Tensor, y: torch.Tensor, batch: int = 512, shuffle_buffer: int = 1000):
+    """tf.data .shuffle(1000).batch(512, drop_remainder=True) in spirit: a windowed shuffle."""
+    n = x.shape[0]
+    order = torch.arange(n, device=x.device)
+    for lo in range(0, n, shuffle_buffer):
+        hi = min(n, lo + shuffle_buffer)
+        order[lo:hi] = order[lo:hi][torch.randperm(hi - lo, device=x.device)]
+    for lo in range(0, n - batch + 1, batch):
+        idx = order[lo: lo + batch]
+        yield x[idx], y[idx]
+
+
+class Trainer(ABC):
+    neural_network: torch.nn.Module
+    optimizer: torch.optim.Optimizer
+
+    # zero-weight masks per layer; class level, as in the reference (trainer.py:25)
+    pruned_indexes_by_layer: Dict[torch.nn.Module, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    @property
+    @abstractmethod
+    def model_name(self) -> str:
+        """The model name."""
+
+    @property
+    @abstractmethod
+    def _layers_to_prune_with_threshold(self) -> Dict[torch.nn.Module, Tuple[float, float]]:
+        """layer -> (weight threshold, bias threshold)."""
+
+    @abstractmethod
+    def _get_error(self, input_data: torch.Tensor, expected_output: torch.Tensor) -> torch.Tensor:
+        """The loss."""
+
+    # ------------------------------------------------------------------ device plumbing
+    @property
+    def device(self) -> torch.device:
+        return next(self.neural_network.parameters()).device
+
+    def _to_device(self, a) -> torch.Tensor:
+        return torch.as_tensor(np.asarray(a)).to(self.device)
+
+    # ------------------------------------------------------------------ the hot path
+    def quantize(self, test_dataset: LeNetDataset, with_cumulative_weight_distribution: bool,
+                 maximum_centroid_bits: int, k_means_initialization_mode: str) -> float:
+        for _layer_name, layer in self.neural_network.get_config().items():
+            quantized_weights_and_bias = []
+            for params in layer.get_weights():
+                cdfs = None
+                if with_cumulative_weight_distribution:
+                    # the reference strips exact zeros with numpy.delete first (trainer.py:55-59);
+                    # the device kernels skip them instead -- same histogram, no compaction
+                    cdfs = utility.get_weight_distribution(params, skip_zeros=True)
+                quantized_weights_and_bias.append(
+                    utility.get_quantized_weight(params, bits=maximum_centroid_bits,
+                                                 mode=k_means_initialization_mode, cdfs=cdfs)[0])
+            layer.set_weights(quantized_weights_and_bias)
+        return self._get_accuracy(test_dataset)
+
+    def _prune_parameters(self, with_standard_deviation_smoothing: bool) -> None:
+        for layer, (weight_threshold, bias_threshold) in self._layers_to_prune_with_threshold.items():
+            weights, biases = layer.get_weights()
+            zero_weight = utility.prune_weigth(weights, threshold=weight_threshold,
+                                               std_smooth=with_standard_deviation_smoothing)
+            zero_bias = utility.prune_weigth(biases, threshold=bias_threshold,
+                                             std_smooth=with_standard_deviation_smoothing)
+            self.pruned_indexes_by_layer[layer] = (zero_weight, zero_bias)
+            layer.set_weights([weights, biases])
+
+    def _reset_pruned_parameters(self) -> None:
+        for layer, (zero_weight, zero_bias) in self.pruned_indexes_by_layer.items():
+            weights, biases = layer.get_weights()
+            ops.apply_mask_(weights, zero_weight)
+            ops.apply_mask_(biases, zero_bias)
+            layer.set_weights([weights, biases])
+
+    # ------------------------------------------------------------------ callers of the path
+    def train(self, train_dataset: LeNetDataset, test_dataset: LeNetDataset, epochs: int) -> List[float]:
+        return self._epochs(train_dataset, test_dataset, epochs, prune=False, reset=False)
+
+    def semi_pruned_train(self, train_dataset: LeNetDataset, test_dataset: LeNetDataset, epochs: int) -> List[float]:
+        return self._epochs(train_dataset, test_dataset, epochs, prune=False, reset=True)
+
+    def pruned_train(self, train_dataset: LeNetDataset, test_dataset: LeNetDataset, epochs: int,
+                     with_standard_deviation_smoothing: bool) -> List[float]:
+        return self._epochs(train_dataset, test_dataset, epochs, prune=True, reset=True,
+                            smoothing=with_standard_deviation_smoothing)
+
+    def _epochs(self, train_dataset, test_dataset, epochs, prune, reset, smoothing=True) -> List[float]:
+        x = self._to_device(train_dataset.input_data).float()
+        y = self._to_device(train_dataset.output_data).float()
+        accuracies = []
+        for _ in range(epochs):
+            for xb, yb in _batches(x, y):
+                if prune:
+                    self._prune_parameters(smoothing)
+                self._apply_gradient(self._get_gradient(xb, yb))
+                if reset:
+                    self._reset_pruned_parameters()
+            accuracies.append(self._get_accuracy(test_dataset))
+        return accuracies
+
+    def store_report(self, directory: str) -> None:
+        """Zero counts per layer (the plots of the reference's report are out of scope)."""
+        pathlib.Path(directory).mkdir(parents=True, exist_ok=True)
+        report = ""
+        for layer_name, layer in self.neural_network.get_config().items():
+            tensors = layer.get_weights()
+            if not tensors:
+                continue
+            weight_layer, bias_layer = tensors
+            report += f"layer: {layer_name}\n"
+            report += f"zeroed weights: {int((weight_layer == 0).sum())}\ntotal weights: {weight_layer.numel()}\n"
+            report += f"zeroed biases: {int((bias_layer == 0).sum())}\ntotal weights: {bias_layer.numel()}\n\n"
+        with open(f"{directory}/report.txt", "w") as f:
+            f.write(report)
+
+    def _get_gradient(self, input_data: torch.Tensor, expected_output: torch.Tensor):
+        self.optimizer.zero_grad(set_to_none=True)
+        loss = self._get_error(input_data, expected_output)
+        loss.backward()
+        return [p.grad for p in self.neural_network.parameters()]
+
+    def _apply_gradient(self, gradient) -> None:
+        for p, g in zip(self.neural_network.parameters(), gradient):
+            p.grad = g
+        self.optimizer.step()
+
+    @torch.no_grad()
+    def _get_accuracy(self, dataset: LeNetDataset) -> float:
+        x = self._to_device(dataset.input_data).float()
+        y = self._to_device(dataset.output_data)
+        pred = torch.argmax(torch.softmax(self.neural_network(x), dim=1), dim=1)
+        return float((pred == y.to(pred.dtype)).float().mean().item())
