@@ -1,0 +1,56 @@
+#!/bin/bash
+# Produce the rocprofv3 evidence for bench.py (run on the GPU box from the repo root):
+#   1. kernel-trace + stats of the benchmark command     -> gpurun_out/profiles/bench_kernel_stats.csv
+#   2. PMC pass FETCH_SIZE, PMC pass WRITE_SIZE (separate) -> HBM bytes per launch of the Lloyd kernel
+export TMPDIR=/tmp
+out=$PWD/gpurun_out/profiles
+rm -rf $out; mkdir -p $out
+CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+python bench.py --steps 5 --warmup 1 > $out/bench_plain.json 2> $out/bench_plain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $CMD > $out/bench_under_trace.json 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $CMD > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $CMD > /dev/null 2>&1
+python - <<'PY'
+import csv, glob, json, os
+out = os.path.join(os.getcwd(), "gpurun_out", "profiles")
+ks = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+rows = list(csv.DictReader(open(ks)))
+with open(os.path.join(out, "bench_kernel_stats.csv"), "w") as f:
+    w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in rows:
+        w.writerow(r)
+def pmc(sub, counter):
+    f = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)[0]
+    vals = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            vals.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+    return vals
+fetch, write = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+summ = {}
+for name, v in fetch.items():
+    if name.startswith("void k_") or name.startswith("k_"):
+        v = sorted(v)
+        # keep launches that did real work (iterations enqueued after convergence return at once)
+        live = [x for x in v if x > 0.3 * v[len(v) // 2]] or v
+        summ[name[:60]] = {"launches": len(live), "FETCH_SIZE_KB_mean": sum(live) / len(live)}
+for name, v in write.items():
+    if name[:60] in summ:
+        summ[name[:60]]["WRITE_SIZE_KB_mean"] = sum(v) / len(v)
+json.dump(summ, open(os.path.join(out, "pmc_hbm_summary.json"), "w"), indent=1)
+acc = [k for k in summ if "k_assign<0" in k]
+traffic = None
+if acc:
+    s = summ[acc[0]]
+    # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM)
+    traffic = 2.0 * s["FETCH_SIZE_KB_mean"] * 1024 + s.get("WRITE_SIZE_KB_mean", 0.0) * 1024
+json.dump({"k_assign_accumulate_hbm_bytes_per_launch": traffic,
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 3 --warmup 1`; "
+                  "bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 half-count correction for 16 B/lane streaming reads) + WRITE_SIZE_KB * 1024; mean over the live launches"},
+          open(os.path.join(out, "traffic.json"), "w"), indent=1)
+print(json.dumps(summ, indent=1)[:1500])
+print("traffic", traffic)
+PY
+head -12 $out/bench_kernel_stats.csv | cut -c1-200
+cat $out/bench_plain.json | cut -c1-600
