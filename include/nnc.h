@@ -190,12 +190,16 @@ int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int 
                       int label_bytes, float *quant_out, float *dist_out, void *stream);
 
 /* Selection of the farthest samples for scikit-learn's empty-cluster relocation
- * (_k_means_common.pyx:167-211: np.argpartition(distances, -n_empty)), on the device:
- * hist4096_dev[b] = #{ i : ((bits(d[i]) >> 19) & 4095) == b } (zeroed here; d >= 0), then all samples
- * in bins >= bin_min are written as keys (bits(d[i]) << 32 | base_index + i) to keys_dev[0..cap) in
- * arbitrary order; count_dev = how many there were (may exceed cap: then nothing is usable). */
-int nnc_topm_hist_f32(const float *d, int64_t n, int64_t *hist4096_dev, void *stream);
-int nnc_topm_compact_f32(const float *d, int64_t n, int32_t bin_min, int64_t base_index, int64_t *keys_dev,
+ * (_k_means_common.pyx:167-211: np.argpartition(distances, -n_empty)), on the device (d >= 0, so the
+ * float32 bits order like the values):
+ *   hist4096_dev[b] = #{ i : (bits(d[i]) >> shift) & (2^width - 1) == b  and, if prefix_shift >= 0,
+ *                            bits(d[i]) >> prefix_shift == prefix }        (zeroed here)
+ *   compact: every sample with bits(d[i]) >= thr_bits is written as the key
+ *   (bits(d[i]) << 32 | base_index + i) to keys_dev[0..cap), arbitrary order; count_dev = how many
+ *   there were (if it exceeds cap the buffer holds only the first cap of them). */
+int nnc_topm_hist_f32(const float *d, int64_t n, int32_t shift, int32_t width, int32_t prefix_shift, uint32_t prefix,
+                      int64_t *hist4096_dev, void *stream);
+int nnc_topm_compact_f32(const float *d, int64_t n, uint32_t thr_bits, int64_t base_index, int64_t *keys_dev,
                          int64_t cap, int64_t *count_dev, void *stream);
 
 /* The relocation edits themselves (_k_means_common.pyx:197-211), as additive changes to the

@@ -9,6 +9,7 @@
 // -ffp-contract=off is REQUIRED: mask bits and centroid indices must reproduce the
 // reference's unfused float32 arithmetic (NumPy / scikit-learn on x86).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -315,8 +316,15 @@ __global__ __launch_bounds__(256) void k_threshold(float *__restrict__ x, int64_
         mask[i] = m;
     }
     if (nzeroed) {
+        // same-address global atomics retire one per ~12 ns: one per workgroup, few workgroups
+        __shared__ unsigned wsum[4];
         for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(nzeroed, (unsigned long long)cnt);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+            if (tot) atomicAdd(nzeroed, (unsigned long long)tot);
+        }
     }
 }
 
@@ -335,7 +343,7 @@ extern "C" int nnc_threshold_mask_f32(float *x, int64_t n, const float *thr_dev,
     if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
     if (n == 0) return NNC_OK;
     const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
-    int grid = stream_grid((n + 3) / 4, 256, 16);
+    int grid = stream_grid((n + 3) / 4, 256, 4);
     if (vec) hipLaunchKernelGGL((k_threshold<true>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
     else hipLaunchKernelGGL((k_threshold<false>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
     LAUNCHCHK("k_threshold");
@@ -550,7 +558,7 @@ extern "C" int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const f
 {
     if (n < 0 || !steps32_dev || !counts_dev || (n > 0 && !x)) return fail(NNC_EINVAL, "nnc_hist31_f32: bad argument");
     if (n == 0) return NNC_OK;
-    int grid = stream_grid((n + 3) / 4, 256, 8);
+    int grid = stream_grid((n + 3) / 4, 256, 2);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     if (vec) hipLaunchKernelGGL((k_hist31<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, steps32_dev, reinterpret_cast<unsigned long long *>(counts_dev));
     else hipLaunchKernelGGL((k_hist31<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, steps32_dev, reinterpret_cast<unsigned long long *>(counts_dev));
@@ -585,7 +593,7 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
     if (n < 0 || k <= 0 || k > NNC_KMAX || !counts_dev || (n > 0 && !labels)) return fail(NNC_EINVAL, "nnc_bincount: bad argument");
     if (label_bytes != 1 && label_bytes != 2) return fail(NNC_EINVAL, "nnc_bincount: label_bytes must be 1 or 2");
     if (n == 0) return NNC_OK;
-    int grid = stream_grid(n, 256 * 8, 8);
+    int grid = stream_grid(n, 256 * 8, 2);
     size_t lds = (size_t)k * 8 * sizeof(unsigned);
     if (label_bytes == 1) hipLaunchKernelGGL((k_bincount<uint8_t>), dim3(grid), dim3(256), lds, S(stream), reinterpret_cast<const uint8_t *>(labels), n, k, reinterpret_cast<unsigned long long *>(counts_dev));
     else hipLaunchKernelGGL((k_bincount<uint16_t>), dim3(grid), dim3(256), lds, S(stream), reinterpret_cast<const uint16_t *>(labels), n, k, reinterpret_cast<unsigned long long *>(counts_dev));
@@ -1504,14 +1512,19 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     if (p->n == 0) return NNC_OK;
     const bool prof = g_prof_on && g_prof_used < g_prof_pool.size();
     if (g_prof_on && !prof) g_prof_skipped++;
-    if (prof) HIPCHK(hipEventRecord(g_prof_pool[g_prof_used].a, S(stream)));
-    if (vec && g_ablation == 1) hipLaunchKernelGGL((k_assign<0, true, uint8_t, 1>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
-    else if (vec && g_ablation == 2) hipLaunchKernelGGL((k_assign<0, true, uint8_t, 2>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
-    else if (vec && g_ablation == 3) hipLaunchKernelGGL((k_assign<0, true, uint8_t, 3>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
-    else if (vec) hipLaunchKernelGGL((k_assign<0, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
-    else hipLaunchKernelGGL((k_assign<0, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr);
+    // hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end (not at the
+    // command processor's arrival), so the difference is the launch's execution time
+    hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
+    hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
+#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr)
+    if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
+    else if (vec && g_ablation == 2) KM_LAUNCH_ACC(true, uint8_t, 2);
+    else if (vec && g_ablation == 3) KM_LAUNCH_ACC(true, uint8_t, 3);
+    else if (vec) KM_LAUNCH_ACC(true, uint8_t);
+    else KM_LAUNCH_ACC(false, uint8_t);
+#undef KM_LAUNCH_ACC
     LAUNCHCHK("k_assign<accumulate>");
-    if (prof) { HIPCHK(hipEventRecord(g_prof_pool[g_prof_used].b, S(stream))); g_prof_used++; }
+    if (prof) g_prof_used++;
     return NNC_OK;
 }
 
@@ -1646,14 +1659,15 @@ extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_para
 // 4b. farthest-sample selection for the empty-cluster relocation
 //
 // The n_empty samples with the largest squared distance to their own centre, out of millions:
-// (1) 4096-bin histogram of the top 12 value bits of the (non-negative) float32 distances, (2) the
-// host picks the lowest bin such that the bins from it upwards hold at least n_empty samples,
-// (3) every sample in those bins is compacted as a 64-bit key (distance bits << 32 | global
-// index) and the few survivors are sorted by the caller.  Keys are unique, so the outcome is
+// (1) 4096-bin histogram of 12 value bits of the (non-negative) float32 distances, starting with
+// the top 12, refined by the next 12 / last 7 inside the cut bin while it is crowded, (2) the host
+// picks the largest threshold that still leaves at least n_empty samples at or above it, (3) those
+// samples are compacted as 64-bit keys (distance bits << 32 | global index) and the few
+// survivors are sorted by the caller.  Keys are unique, so the outcome is
 // deterministic: descending distance, equal distances by descending index.
 // ======================================================================================
-__global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, int64_t n,
-                                                   unsigned long long *__restrict__ hist)
+__global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, int64_t n, int shift, unsigned mask, int pshift,
+                                                   unsigned prefix, unsigned long long *__restrict__ hist)
 {
     __shared__ unsigned h[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
@@ -1664,12 +1678,13 @@ __global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, 
     const uint4 *d4 = reinterpret_cast<const uint4 *>(d);
     // most distances are tiny and share a handful of bins: count runs of equal bins in registers
     unsigned run_bin = 0xFFFFFFFFu, run_cnt = 0;
-#define TH1(u) do { unsigned b_ = ((u) >> 19) & 4095u; if (b_ != run_bin) { if (run_cnt) atomicAdd(&h[run_bin], run_cnt); run_bin = b_; run_cnt = 0; } run_cnt++; } while (0)
+#define TH1(u) do { const unsigned u_ = (u); if (pshift < 0 || (u_ >> pshift) == prefix) { const unsigned b_ = (u_ >> shift) & mask; \
+        if (b_ != run_bin) { if (run_cnt) atomicAdd(&h[run_bin], run_cnt); run_bin = b_; run_cnt = 0; } run_cnt++; } } while (0)
     for (int64_t v = tid; v < nvec; v += nthreads) {
         const uint4 a = d4[v];
         TH1(a.x); TH1(a.y); TH1(a.z); TH1(a.w);
     }
-    for (int64_t i = (nvec << 2) + tid; i < n; i += nthreads) { const unsigned u = __float_as_uint(d[i]); TH1(u); }
+    for (int64_t i = (nvec << 2) + tid; i < n; i += nthreads) TH1(__float_as_uint(d[i]));
 #undef TH1
     if (run_cnt) atomicAdd(&h[run_bin], run_cnt);
     __syncthreads();
@@ -1677,7 +1692,7 @@ __global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, 
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-__global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ d, int64_t n, unsigned bin_min,
+__global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ d, int64_t n, unsigned thr_bits,
                                                       long long base_index, long long *__restrict__ keys,
                                                       long long cap, unsigned long long *__restrict__ count)
 {
@@ -1685,33 +1700,36 @@ __global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ 
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = tid; i < n; i += nthreads) {
         const unsigned u = __float_as_uint(d[i]);
-        if (((u >> 19) & 4095u) >= bin_min) {
+        if (u >= thr_bits) {
             const unsigned long long slot = atomicAdd(count, 1ull);
             if ((long long)slot < cap) keys[slot] = ((long long)u << 32) | (base_index + i);
         }
     }
 }
 
-extern "C" int nnc_topm_hist_f32(const float *d, int64_t n, int64_t *hist4096_dev, void *stream)
+extern "C" int nnc_topm_hist_f32(const float *d, int64_t n, int32_t shift, int32_t width, int32_t prefix_shift, uint32_t prefix,
+                                 int64_t *hist4096_dev, void *stream)
 {
-    if (n < 0 || !hist4096_dev || (n > 0 && !d)) return fail(NNC_EINVAL, "nnc_topm_hist_f32: bad argument");
+    if (n < 0 || !hist4096_dev || (n > 0 && !d) || shift < 0 || shift > 31 || prefix_shift > 31 || width < 1 || width > 12)
+        return fail(NNC_EINVAL, "nnc_topm_hist_f32: bad argument");
     HIPCHK(hipMemsetAsync(hist4096_dev, 0, 4096 * sizeof(int64_t), S(stream)));
     if (n == 0) return NNC_OK;
-    int grid = stream_grid((n + 3) / 4, 256, 8);
-    hipLaunchKernelGGL(k_topm_hist, dim3(grid), dim3(256), 0, S(stream), d, n, reinterpret_cast<unsigned long long *>(hist4096_dev));
+    int grid = stream_grid((n + 3) / 4, 256, 2);
+    hipLaunchKernelGGL(k_topm_hist, dim3(grid), dim3(256), 0, S(stream), d, n, (int)shift, (1u << width) - 1u, (int)prefix_shift, (unsigned)prefix,
+                       reinterpret_cast<unsigned long long *>(hist4096_dev));
     LAUNCHCHK("k_topm_hist");
     return NNC_OK;
 }
 
-extern "C" int nnc_topm_compact_f32(const float *d, int64_t n, int32_t bin_min, int64_t base_index, int64_t *keys_dev,
+extern "C" int nnc_topm_compact_f32(const float *d, int64_t n, uint32_t thr_bits, int64_t base_index, int64_t *keys_dev,
                                     int64_t cap, int64_t *count_dev, void *stream)
 {
-    if (n < 0 || !keys_dev || !count_dev || cap <= 0 || bin_min < 0 || bin_min > 4095 || (n > 0 && !d))
+    if (n < 0 || !keys_dev || !count_dev || cap <= 0 || (n > 0 && !d))
         return fail(NNC_EINVAL, "nnc_topm_compact_f32: bad argument");
     HIPCHK(hipMemsetAsync(count_dev, 0, sizeof(int64_t), S(stream)));
     if (n == 0) return NNC_OK;
     int grid = stream_grid(n, 256 * 4, 8);
-    hipLaunchKernelGGL(k_topm_compact, dim3(grid), dim3(256), 0, S(stream), d, n, (unsigned)bin_min, (long long)base_index,
+    hipLaunchKernelGGL(k_topm_compact, dim3(grid), dim3(256), 0, S(stream), d, n, (unsigned)thr_bits, (long long)base_index,
                        reinterpret_cast<long long *>(keys_dev), (long long)cap, reinterpret_cast<unsigned long long *>(count_dev));
     LAUNCHCHK("k_topm_compact");
     return NNC_OK;

@@ -20,6 +20,7 @@ all-reduce (2K int64) per iteration.
 from __future__ import annotations
 
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -194,7 +195,7 @@ class DeviceKMeans:
             top = torch.topk(allk, min(m, int((allk >= 0).sum().item())), largest=True, sorted=True).values
         return top, None
 
-    TOPM_CAP = 1 << 18
+    TOPM_CAP = 1 << 16
 
     def _local_top_keys(self, d: torch.Tensor, m: int, base: int) -> torch.Tensor:
         """The m largest keys (float32 bits of d) << 32 | (base + index) of this shard, descending:
@@ -202,18 +203,26 @@ class DeviceKMeans:
         (HIP kernels) -> sort of the survivors."""
         n = d.numel()
         hist = torch.empty(4096, dtype=torch.int64, device=self.dev)
-        nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, hist.data_ptr(), self.stream))
-        h = hist.cpu().numpy()
-        above = np.cumsum(h[::-1])[::-1]            # samples in bins >= b
-        ok = np.nonzero(above >= m)[0]
-        bin_min = int(ok[-1]) if ok.size else 0      # highest bin that still leaves >= m samples
-        cand = int(above[bin_min])
+        prefix, decided, thr_bits, cand = None, 0, 0, n
+        for shift, width, pshift in ((19, 12, -1), (7, 12, 19), (0, 7, 7)):   # 12 + 12 + 7 value bits (sign bit is 0)
+            nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, shift, width, pshift, 0 if prefix is None else prefix,
+                                               hist.data_ptr(), self.stream))
+            h = hist.cpu().numpy()
+            above = np.cumsum(h[::-1])[::-1] + decided           # samples at or above bin b (within the prefix) + those above the prefix
+            ok = np.nonzero(above >= m)[0]
+            b = int(ok[-1]) if ok.size else 0                    # highest bin that still leaves >= m samples
+            cand = int(above[b])
+            decided = int(above[b + 1]) if b + 1 < above.size else decided
+            prefix = b if prefix is None else ((prefix << width) | b)
+            thr_bits = prefix << shift
+            if cand <= self.TOPM_CAP:
+                break
         if cand <= self.TOPM_CAP:
             keys = torch.empty(cand, dtype=torch.int64, device=self.dev)
             cnt = torch.zeros(1, dtype=torch.int64, device=self.dev)
-            nat.check(self.L.nnc_topm_compact_f32(d.data_ptr(), n, bin_min, int(base), keys.data_ptr(), cand, cnt.data_ptr(), self.stream))
+            nat.check(self.L.nnc_topm_compact_f32(d.data_ptr(), n, thr_bits, int(base), keys.data_ptr(), cand, cnt.data_ptr(), self.stream))
             return torch.sort(keys, descending=True).values[:m]
-        # a heavily populated cut bin (massive ties): general selection over all keys
+        # a crowd of exactly equal distances at the cut: general selection over all keys
         idx = torch.arange(base, base + n, dtype=torch.int64, device=self.dev)
         key = (d.view(torch.int32).to(torch.int64) << 32) | idx
         return torch.topk(key, m, largest=True, sorted=True).values
@@ -269,6 +278,7 @@ class DeviceKMeans:
         values = cluster_centers_[labels_] as a device float32 vector (utility.py:239)."""
         strict_labels = None
         batch = self.batch
+        hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
         while True:
             self.iterate(batch)
             st = self.status()
@@ -280,8 +290,17 @@ class DeviceKMeans:
                 if int(st.done) == 3:
                     strict_labels = self._reloc_labels
                 batch = 1
+                hist = []
             else:
+                # size the next batch so that it ends about where the shift crosses the tolerance
+                # (launches enqueued after convergence are no-ops, but they still cost a dispatch)
+                hist.append((int(st.iter), float(st.shift_tot)))
                 batch = min(self.batch, batch * 2)
+                if len(hist) >= 2 and hist[-1][1] > 0 and hist[-2][1] > hist[-1][1] and self.tol_ > 0:
+                    (i0, s0), (i1, s1) = hist[-2], hist[-1]
+                    rate = math.log(s0 / s1) / max(1, i1 - i0)          # log-decay per iteration
+                    left = math.log(s1 / float(self.tol_)) / rate if s1 > float(self.tol_) else 0.0
+                    batch = int(max(1, min(self.batch, math.floor(left * 0.9))))
             if st.done:
                 break
         stop = {1: "tol", 2: "max_iter", 3: "strict"}.get(int(st.done), "?")

@@ -355,3 +355,23 @@ def test_full_size_25m_k256_properties(nnc):
     # counts add up; each centre is the mean of its members to 1e-6 relative of the data scale
     counts = np.bincount(labels, minlength=k)
     assert counts.sum() == n
+
+
+def test_farthest_selection_rule(nnc):
+    """The device selection equals 'descending distance, ties by descending index' on crowded and
+    sparse distance distributions (it refines the histogram inside the cut bin when needed)."""
+    rng = np.random.RandomState(5)
+    n = 3_000_000
+    cases = {
+        "uniform": rng.rand(n).astype(np.float32) * 1e-6,
+        "ties": np.round(rng.rand(n) * 50).astype(np.float32) * 1e-3,
+        "tail": (rng.randn(n).astype(np.float32) ** 2) * 1e-4,
+    }
+    init = np.linspace(-1, 1, 8).astype(np.float32)
+    km = nnc.kmeans.DeviceKMeans(dev(nnc, rng.rand(n).astype(np.float32)), init)
+    for name, d in cases.items():
+        for m in (1, 7, 150):
+            keys = km._local_top_keys(dev(nnc, d), m, 0).cpu().numpy()
+            idx = keys & 0xFFFFFFFF
+            want = np.lexsort((np.arange(n), d))[::-1][:m]
+            assert np.array_equal(idx, want), (name, m)
