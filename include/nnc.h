@@ -157,7 +157,7 @@ typedef struct nnc_kmeans_status {
     float shift_tot;   /* last sum of squared centre shifts (float32, NumPy order) */
     float tol;
     int32_t k;
-    int32_t reserved;
+    int32_t same_counts; /* 1: every cluster has as many members as in the previous iteration (labels MAY be equal) */
 } nnc_kmeans_status;
 
 int32_t nnc_fix_shift(float absmax, int64_t n_total);

@@ -44,7 +44,7 @@ class KMeansParams(ctypes.Structure):
 class KMeansStatus(ctypes.Structure):
     _fields_ = [
         ("iter", c_i32), ("done", c_i32), ("paused", c_i32), ("n_empty", c_i32),
-        ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("reserved", c_i32),
+        ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("same_counts", c_i32),
     ]
 
 

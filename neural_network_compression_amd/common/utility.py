@@ -136,14 +136,13 @@ def _init_space(x: torch.Tensor, n: int, bits: int, mode: str, cdfs):
         host = mm.cpu().numpy()
         return np.linspace(np.float32(host[0]), np.float32(host[1]), num=2 ** bits)
     if mode == "density" and cdfs is not None:
+        # for each target t in linspace(0, 1, 2**bits + 1): the x of the FIRST cdf value closest to t.
+        # The reference does this with python's min(key=abs(y - t)) and argmax(y == min)
+        # (utility.py:212-221); argmin over the same float64 |y - t| picks the same first minimum.
         tmp = np.linspace(0, 1, num=(2 ** bits) + 1)
-        xval, yval = cdfs[0], cdfs[1]
-        space = []
-        for i in range(len(tmp)):
-            minval = min(yval, key=lambda v: abs(v - tmp[i]))
-            idx_val = np.argmax(yval == minval)
-            space.append(xval[idx_val])
-        return np.array(space)
+        xval, yval = np.asarray(cdfs[0]), np.asarray(cdfs[1], dtype=np.float64)
+        idx = np.abs(yval[None, :] - tmp[:, None]).argmin(axis=1)
+        return np.array([xval[i] for i in idx])
     if mode == "forgy":
         # np.random.choice(flat, size=K) draws K indices with the legacy global RNG
         # (randint(0, N, K)) and gathers; draw the same indices, gather on the device

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 #include <string>
@@ -648,6 +649,7 @@ struct KmWs {
     float c[2][NNC_KMAX];        // centred centres in ORIGINAL index order; [cur] current, [cur^1] previous
     long long partials[2 * NNC_KMAX]; // sums then counts, original index order (all-reduced across ranks)
     long long partials_local[2 * NNC_KMAX]; // this rank's own sums/counts of the last accumulated iteration
+    long long prev_counts[NNC_KMAX];        // label counts of the previous iteration (before any relocation edit)
     long long shard_sum[KM_NSHARD][NNC_KMAX]; // sorted index order of tab[cur]
     unsigned long long shard_cnt[KM_NSHARD][NNC_KMAX];
     KmTab tab[2];
@@ -1145,6 +1147,15 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     __syncthreads();
     FSTAMP(1);
 
+    if (mode != FIN_INIT && !resume) {
+        // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept
+        // its count; the host runs the full label comparison (strict convergence) only then.
+        int diff = 0;
+        for (int j = tid; j < k; j += KM_THREADS) { diff |= (cnt_o[j] != ws->prev_counts[j]); ws->prev_counts[j] = cnt_o[j]; }
+        const int any_diff = __syncthreads_or(diff);
+        if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
+    }
+
     if (mode != FIN_INIT) {
         // ---- empty clusters?  (one barrier-with-count)
         int my_empty = 0;
@@ -1380,7 +1391,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     const int tid = threadIdx.x;
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
-        ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.reserved = 0;
+        ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
         ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
@@ -1391,6 +1402,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
         (&ws->shard_sum[0][0])[i] = 0; (&ws->shard_cnt[0][0])[i] = 0;
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
+    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) ws->prev_counts[i] = -1;
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -1420,9 +1432,10 @@ static int km_grid(int64_t n, size_t lds_bytes)
     int64_t blocks = ((n + 7) / 8 + KM_THREADS - 1) / KM_THREADS;
     if (blocks < 1) blocks = 1;
     int per_cu = (lds_bytes + 1024 <= 80 * 1024) ? 2 : 1; // two 1024-thread workgroups fit a CU if LDS allows
-    return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu);
+    static int mult_q = -1; // tuning knob: workgroups per resident slot, in quarters (NNC_KM_GRID_QUARTERS)
+    if (mult_q < 0) { const char *e = getenv("NNC_KM_GRID_QUARTERS"); mult_q = e ? atoi(e) : 4; if (mult_q < 1) mult_q = 4; }
+    return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu * mult_q / 4);
 }
-
 
 // --------------------------------------------------------------------------------------
 // optional in-library profiler: HIP events around every launch of the Lloyd streaming

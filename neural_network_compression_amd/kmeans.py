@@ -243,7 +243,8 @@ class DeviceKMeans:
         lab, _, d = self.assign(which=0, labels=True, distances=True)
         lb = 1 if self.k <= 256 else 2
         flag = None
-        if st.iter >= 1:
+        if st.iter >= 1 and st.same_counts:
+            # labels can only equal the previous iteration's if no cluster changed size
             prev, _, _ = self.assign(which=1, labels=True)
             flag = torch.empty(1, dtype=torch.int32, device=self.dev)
             nat.check(self.L.nnc_labels_equal(lab.data_ptr(), prev.data_ptr(), self.n, lb, flag.data_ptr(), self.stream))
