@@ -52,7 +52,7 @@ def parse():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--mode", default="density")
     ap.add_argument("--q", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 

@@ -119,3 +119,36 @@ def test_compress_layer_pipeline_matches_oracle(trainer_mod):
     assert np.array_equal(res.counts, counts)
     ol, oh, ot = orc.huffman_lengths(counts)
     assert np.array_equal(res.code_lengths, ol) and res.total_bits == ot
+
+
+def test_sharded_code_path_with_one_rank_group(trainer_mod):
+    """The torch.distributed branch (RCCL all-reduce of the 2K int64 partials, chunk-sum
+    all-gather, sharded CDF / init / relocation) on a 1-rank NCCL group: same results as the
+    plain single-GPU path."""
+    import torch.distributed as dist
+
+    _, _, _, pipeline = trainer_mod
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+        created = True
+    try:
+        group = dist.group.WORLD
+        w = synth.weights((300_000,), 7100)
+        for bits, mode, q in [(4, "density", 1), (5, "forgy", 1), (4, "linear", 1)]:
+            np.random.seed(11)
+            a = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=q, bits=bits, mode=mode)
+            np.random.seed(11)
+            b = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=q, bits=bits, mode=mode, group=group)
+            assert a.nzeroed == b.nzeroed and a.sigma == b.sigma
+            assert torch.equal(a.mask, b.mask)
+            assert a.model.n_iter_ == b.model.n_iter_ and a.model.n_relocations_ == b.model.n_relocations_
+            assert np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_)
+            assert np.array_equal(a.model.labels_, b.model.labels_)
+            assert torch.equal(a.values, b.values)
+            assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
+    finally:
+        if created:
+            dist.destroy_process_group()
