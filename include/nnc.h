@@ -194,23 +194,21 @@ int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int 
  * float32 bits order like the values):
  *   hist4096_dev[b] = #{ i : (bits(d[i]) >> shift) & (2^width - 1) == b  and, if prefix_shift >= 0,
  *                            bits(d[i]) >> prefix_shift == prefix }        (zeroed here)
- *   compact: every sample with bits(d[i]) >= thr_bits is written as the key
- *   (bits(d[i]) << 32 | base_index + i) to keys_dev[0..cap), arbitrary order; count_dev = how many
- *   there were (if it exceeds cap the buffer holds only the first cap of them). */
+ *   compact: every sample with bits(d[i]) >= thr_bits is written as the 64-bit key
+ *   (bits(d[i]) << 32 | order-preserving bits of x[i]) to keys_dev[0..cap), arbitrary order;
+ *   count_dev = how many there were (if it exceeds cap the buffer holds only the first cap of
+ *   them).  Sorting the keys in descending order ranks the samples by distance, equal distances
+ *   by value; samples equal in both are interchangeable.  d and x are in the same order (any). */
 int nnc_topm_hist_f32(const float *d, int64_t n, int32_t shift, int32_t width, int32_t prefix_shift, uint32_t prefix,
                       int64_t *hist4096_dev, void *stream);
-int nnc_topm_compact_f32(const float *d, int64_t n, uint32_t thr_bits, int64_t base_index, int64_t *keys_dev,
+int nnc_topm_compact_f32(const float *d, const float *x, int64_t n, uint32_t thr_bits, int64_t *keys_dev,
                          int64_t cap, int64_t *count_dev, void *stream);
 
 /* The relocation edits themselves (_k_means_common.pyx:197-211), as additive changes to the
- * per-cluster sums/counts: keys_sorted_dev = the selected samples' keys in descending order
- * (nkeys of them); the i-th empty cluster of the workspace's partials takes the i-th sample.
- * delta_dev (int64[2k], zeroed by the caller) receives the changes for the samples this rank
- * owns (global index in [base_index, base_index + n_local)); the caller sums the ranks' deltas
- * and adds them to nnc_kmeans_partials().  x / labels: this rank's shard and its current labels. */
-int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, const float *x,
-                        const void *labels, int label_bytes, int64_t base_index, int64_t n_local,
-                        int64_t *delta_dev, void *stream);
+ * per-cluster sums/counts in nnc_kmeans_partials(): keys_sorted_dev = the selected samples' keys
+ * in descending order (nkeys of them, the same on every rank); the i-th empty cluster takes the
+ * i-th sample, whose value travels in the key and whose current cluster is re-derived exactly. */
+int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream);
 /* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence
  * test, _kmeans.py:717); nnc_kmeans_set_done_if sets done = done_code when *flag_dev != 0. */
 int nnc_labels_equal(const void *a, const void *b, int64_t n, int label_bytes, int32_t *flag_dev, void *stream);

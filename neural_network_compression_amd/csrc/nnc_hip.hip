@@ -1705,9 +1705,19 @@ __global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, 
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
 }
 
-__global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ d, int64_t n, unsigned thr_bits,
-                                                      long long base_index, long long *__restrict__ keys,
-                                                      long long cap, unsigned long long *__restrict__ count)
+__device__ __forceinline__ unsigned f32_ordered_bits(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // unsigned order == float order
+}
+__device__ __forceinline__ float f32_from_ordered_bits(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+__global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ d, const float *__restrict__ x, int64_t n,
+                                                      unsigned thr_bits, long long *__restrict__ keys, long long cap,
+                                                      unsigned long long *__restrict__ count)
 {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
@@ -1715,7 +1725,7 @@ __global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ 
         const unsigned u = __float_as_uint(d[i]);
         if (u >= thr_bits) {
             const unsigned long long slot = atomicAdd(count, 1ull);
-            if ((long long)slot < cap) keys[slot] = ((long long)u << 32) | (base_index + i);
+            if ((long long)slot < cap) keys[slot] = ((long long)u << 32) | (long long)f32_ordered_bits(x[i]);
         }
     }
 }
@@ -1734,34 +1744,35 @@ extern "C" int nnc_topm_hist_f32(const float *d, int64_t n, int32_t shift, int32
     return NNC_OK;
 }
 
-extern "C" int nnc_topm_compact_f32(const float *d, int64_t n, uint32_t thr_bits, int64_t base_index, int64_t *keys_dev,
+extern "C" int nnc_topm_compact_f32(const float *d, const float *x, int64_t n, uint32_t thr_bits, int64_t *keys_dev,
                                     int64_t cap, int64_t *count_dev, void *stream)
 {
-    if (n < 0 || !keys_dev || !count_dev || cap <= 0 || (n > 0 && !d))
+    if (n < 0 || !keys_dev || !count_dev || cap <= 0 || (n > 0 && (!d || !x)))
         return fail(NNC_EINVAL, "nnc_topm_compact_f32: bad argument");
     HIPCHK(hipMemsetAsync(count_dev, 0, sizeof(int64_t), S(stream)));
     if (n == 0) return NNC_OK;
     int grid = stream_grid(n, 256 * 4, 8);
-    hipLaunchKernelGGL(k_topm_compact, dim3(grid), dim3(256), 0, S(stream), d, n, (unsigned)thr_bits, (long long)base_index,
+    hipLaunchKernelGGL(k_topm_compact, dim3(grid), dim3(256), 0, S(stream), d, x, n, (unsigned)thr_bits,
                        reinterpret_cast<long long *>(keys_dev), (long long)cap, reinterpret_cast<unsigned long long *>(count_dev));
     LAUNCHCHK("k_topm_compact");
     return NNC_OK;
 }
 
-// apply scikit-learn's relocation (_k_means_common.pyx:197-211) as additive edits: the i-th empty
-// cluster (ascending index) takes the i-th key's sample; that sample's old cluster gives it up.
-// delta[0..k) sums, delta[k..2k) counts; only samples this rank owns are applied (the ranks'
-// deltas are summed by the caller).  Nothing happens when the largest distance is zero.
-template <typename LT>
-__global__ __launch_bounds__(KM_THREADS) void k_relocate(const KmWs *__restrict__ ws, const long long *__restrict__ keys,
-                                                         int nkeys, const float *__restrict__ x,
-                                                         const LT *__restrict__ labels, long long base, long long n_local,
-                                                         long long *__restrict__ delta)
+// apply scikit-learn's relocation (_k_means_common.pyx:197-211) as additive edits to the
+// (already global) per-cluster sums/counts: the i-th empty cluster (ascending index) takes the
+// i-th key's sample; that sample's old cluster gives it up.  A key carries the sample's value
+// (low 32 bits, order-preserving float bits); its cluster is re-derived with scikit-learn's exact
+// float32 expression over all centres.  Every rank applies the same edits to its copy.
+// Nothing happens when the largest distance is zero.
+__global__ __launch_bounds__(KM_THREADS) void k_relocate(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys)
 {
     __shared__ int empty_id[NNC_KMAX];
     __shared__ int wave_cnt[KM_THREADS / 64];
+    __shared__ float cen[NNC_KMAX];
     const int tid = threadIdx.x;
     const int k = ws->p.k;
+    const float *ccur = ws->c[ws->cur];
+    for (int j = tid; j < k; j += KM_THREADS) cen[j] = ccur[j];
     // ordered list of the empty clusters
     const int rounds = (k + KM_THREADS - 1) / KM_THREADS;
     int carry = 0;
@@ -1786,32 +1797,29 @@ __global__ __launch_bounds__(KM_THREADS) void k_relocate(const KmWs *__restrict_
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
     for (int i = tid; i < m; i += KM_THREADS) {
-        const long long gidx = keys[i] & 0xFFFFFFFFll;
-        if (gidx >= base && gidx < base + n_local) {
-            const long long li = gidx - base;
-            const long long v = (long long)fix_f32(x[li] - mean, Sft);
-            const int old = (int)labels[li], nw = empty_id[i];
-            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[old]), (unsigned long long)(-v));
-            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[nw]), (unsigned long long)v);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[k + nw]), 1ull);
-            atomicAdd(reinterpret_cast<unsigned long long *>(&delta[k + old]), (unsigned long long)(-1ll));
+        const float xv = f32_from_ordered_bits((unsigned)(keys[i] & 0xFFFFFFFFll));
+        const float xc = xv - mean;
+        float best = cen[0] * cen[0] + (-2.0f * (xc * cen[0]));
+        int old = 0;
+        for (int j = 1; j < k; j++) {
+            const float dj = cen[j] * cen[j] + (-2.0f * (xc * cen[j]));
+            if (dj < best) { best = dj; old = j; }
         }
+        const long long v = (long long)fix_f32(xc, Sft);
+        const int nw = empty_id[i];
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[old]), (unsigned long long)(-v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[nw]), (unsigned long long)v);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[k + nw]), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[k + old]), (unsigned long long)(-1ll));
     }
 }
 
-extern "C" int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, const float *x,
-                                   const void *labels, int label_bytes, int64_t base_index, int64_t n_local,
-                                   int64_t *delta_dev, void *stream)
+extern "C" int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream)
 {
-    if (!ws || !keys_sorted_dev || nkeys < 0 || !delta_dev || (n_local > 0 && (!x || !labels)))
-        return fail(NNC_EINVAL, "nnc_kmeans_relocate: bad argument");
-    if (label_bytes != 1 && label_bytes != 2) return fail(NNC_EINVAL, "nnc_kmeans_relocate: label_bytes must be 1 or 2");
+    if (!ws || !keys_sorted_dev || nkeys < 0) return fail(NNC_EINVAL, "nnc_kmeans_relocate: bad argument");
     if (nkeys == 0) return NNC_OK;
-    const KmWs *w = reinterpret_cast<const KmWs *>(ws);
-    if (label_bytes == 1)
-        hipLaunchKernelGGL((k_relocate<uint8_t>), dim3(1), dim3(KM_THREADS), 0, S(stream), w, reinterpret_cast<const long long *>(keys_sorted_dev), nkeys, x, reinterpret_cast<const uint8_t *>(labels), (long long)base_index, (long long)n_local, reinterpret_cast<long long *>(delta_dev));
-    else
-        hipLaunchKernelGGL((k_relocate<uint16_t>), dim3(1), dim3(KM_THREADS), 0, S(stream), w, reinterpret_cast<const long long *>(keys_sorted_dev), nkeys, x, reinterpret_cast<const uint16_t *>(labels), (long long)base_index, (long long)n_local, reinterpret_cast<long long *>(delta_dev));
+    hipLaunchKernelGGL(k_relocate, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws),
+                       reinterpret_cast<const long long *>(keys_sorted_dev), nkeys);
     LAUNCHCHK("k_relocate");
     return NNC_OK;
 }

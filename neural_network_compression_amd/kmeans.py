@@ -124,7 +124,10 @@ class DeviceKMeans:
         off = pptr - self.ws.data_ptr()
         self.partials = self.ws[off: off + 16 * self.k].view(torch.int64)
         self.n_relocations = 0
-        self._status_host = nat.KMeansStatus()
+        # pinned host landing zones for the small device->host reads (status block, 4096-bin histogram)
+        self._status_pin = torch.empty(ctypes.sizeof(nat.KMeansStatus), dtype=torch.uint8, pin_memory=True)
+        self._status_host = nat.KMeansStatus.from_address(self._status_pin.data_ptr())
+        self._hist_pin = torch.empty(4096, dtype=torch.int64, pin_memory=True)
         # The iterations stream a value-sorted copy (same sums in any order, far fewer LDS atomics);
         # labels, values and relocation distances always come from the original vector.
         if sort is None:
@@ -157,6 +160,11 @@ class DeviceKMeans:
             nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 0, self.stream))
 
     def assign(self, which: int = 0, labels: bool = True, values: bool = False, distances: bool = False):
+        """E-step on the ORIGINAL vector: labels / cluster_centers_[labels_] / squared distances."""
+        return self._assign_on(self.x, which, labels, values, distances)
+
+    def _assign_on(self, src: torch.Tensor, which: int = 0, labels: bool = True, values: bool = False,
+                   distances: bool = False):
         lab = q = d = None
         lb = 1 if self.k <= 256 else 2
         if labels:
@@ -165,7 +173,7 @@ class DeviceKMeans:
             q = torch.empty(self.n, dtype=torch.float32, device=self.dev)
         if distances:
             d = torch.empty(self.n, dtype=torch.float32, device=self.dev)
-        nat.check(self.L.nnc_kmeans_assign(self.x.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(which),
+        nat.check(self.L.nnc_kmeans_assign(src.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(which),
                                            ops._ptr(lab), lb, ops._ptr(q), ops._ptr(d), self.stream))
         return lab, q, d
 
@@ -175,39 +183,27 @@ class DeviceKMeans:
         return out.cpu().numpy()
 
     # -------------------------------------------------------------- empty-cluster relocation
-    def _farthest(self, d: torch.Tensor, m: int, base: int):
-        """Indices (global) and squared distances of the m samples farthest from their centre, in
-        descending order of distance, equal distances by descending index.  The ordering key is
-        the 64-bit integer (float32 bits of d) << 32 | global index (d >= 0, so its bits sort
-        like its value); keys are unique, so the selection is deterministic on any device count."""
-        n = d.numel()
-        m_loc = min(m, n)
-        top = self._local_top_keys(d, m_loc, base) if m_loc else torch.empty(0, dtype=torch.int64, device=self.dev)
-        if self.group is not None:
-            import torch.distributed as dist
-
-            world = dist.get_world_size(self.group)
-            pad = torch.full((m,), -1, dtype=torch.int64, device=self.dev)
-            pad[:m_loc] = top
-            bufs = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(bufs, pad, group=self.group)
-            allk = torch.cat(bufs)
-            top = torch.topk(allk, min(m, int((allk >= 0).sum().item())), largest=True, sorted=True).values
-        return top, None
-
     TOPM_CAP = 1 << 16
 
-    def _local_top_keys(self, d: torch.Tensor, m: int, base: int) -> torch.Tensor:
-        """The m largest keys (float32 bits of d) << 32 | (base + index) of this shard, descending:
-        histogram of the top value bits -> cut bin -> compaction of the few samples above the cut
-        (HIP kernels) -> sort of the survivors."""
+    def _top_keys(self, d: torch.Tensor, x: torch.Tensor, m: int) -> torch.Tensor:
+        """Keys of the m samples farthest from their own centre (this shard), descending.  A key is
+        (float32 bits of d) << 32 | order-preserving bits of x: descending keys = descending
+        distance, equal distances by descending value; samples equal in both are interchangeable,
+        so the outcome does not depend on sample order or on how the vector is sharded.
+        Histogram of the distance bits -> threshold -> compaction of the survivors (HIP kernels,
+        refined inside the cut bin while it is crowded) -> sort of the few survivors."""
         n = d.numel()
+        m = min(m, n)
+        if m == 0:
+            return torch.empty(0, dtype=torch.int64, device=self.dev)
         hist = torch.empty(4096, dtype=torch.int64, device=self.dev)
         prefix, decided, thr_bits, cand = None, 0, 0, n
         for shift, width, pshift in ((19, 12, -1), (7, 12, 19), (0, 7, 7)):   # 12 + 12 + 7 value bits (sign bit is 0)
             nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, shift, width, pshift, 0 if prefix is None else prefix,
                                                hist.data_ptr(), self.stream))
-            h = hist.cpu().numpy()
+            self._hist_pin.copy_(hist, non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()
+            h = self._hist_pin.numpy()
             above = np.cumsum(h[::-1])[::-1] + decided           # samples at or above bin b (within the prefix) + those above the prefix
             ok = np.nonzero(above >= m)[0]
             b = int(ok[-1]) if ok.size else 0                    # highest bin that still leaves >= m samples
@@ -220,58 +216,56 @@ class DeviceKMeans:
         if cand <= self.TOPM_CAP:
             keys = torch.empty(cand, dtype=torch.int64, device=self.dev)
             cnt = torch.zeros(1, dtype=torch.int64, device=self.dev)
-            nat.check(self.L.nnc_topm_compact_f32(d.data_ptr(), n, thr_bits, int(base), keys.data_ptr(), cand, cnt.data_ptr(), self.stream))
+            nat.check(self.L.nnc_topm_compact_f32(d.data_ptr(), x.data_ptr(), n, thr_bits, keys.data_ptr(), cand, cnt.data_ptr(), self.stream))
             return torch.sort(keys, descending=True).values[:m]
         # a crowd of exactly equal distances at the cut: general selection over all keys
-        idx = torch.arange(base, base + n, dtype=torch.int64, device=self.dev)
-        key = (d.view(torch.int32).to(torch.int64) << 32) | idx
+        xb = x.view(torch.int32).to(torch.int64)
+        ordered = torch.where(xb < 0, (~xb) & 0xFFFFFFFF, xb | 0x80000000)
+        key = (d.view(torch.int32).to(torch.int64) << 32) | ordered
         return torch.topk(key, m, largest=True, sorted=True).values
 
     def _relocate_and_resume(self, st) -> None:
         """scikit-learn's _relocate_empty_clusters_dense (_k_means_common.pyx:167-211) for a
-        paused iteration, then resume the finalize step; everything is enqueued on the device
-        (one small host read, the 4096-bin distance histogram).  If the labels of this iteration
-        equal those of the previous one the state is marked done = 3 (strict convergence).
+        paused iteration, then resume the finalize step; everything runs on the device (one small
+        host read, the 4096-bin distance histogram).  If the labels of this iteration equal those
+        of the previous one the state is marked done = 3 (strict convergence).
 
-        Distances, labels and the selection of the n_empty farthest samples are computed on the
-        device; the i-th empty cluster (ascending index) receives the i-th farthest sample.
-        scikit-learn pairs them in the order numpy.argpartition happens to leave the top of its
-        index array in -- the same SET of samples, the same pairing whenever n_empty == 1, and an
-        implementation-defined (CPU-dispatch dependent) pairing otherwise; descending distance is
-        what that order most often is, and it is the rule of the oracle's mode B."""
+        The i-th empty cluster (ascending index) receives the i-th farthest sample in the order
+        "descending distance, equal distances by descending value".  scikit-learn pairs them in the
+        order numpy.argpartition happens to leave the top of its index array in: the same set of
+        samples (up to ties at the cut), the same pairing whenever n_empty == 1, an implementation-
+        defined (CPU-dispatch dependent) pairing otherwise."""
         n_empty = int(st.n_empty)
-        lab, _, d = self.assign(which=0, labels=True, distances=True)
-        lb = 1 if self.k <= 256 else 2
+        xs = self.x_iter  # any order will do; the value-sorted copy makes the histogram cheap
+        _, _, d = self._assign_on(xs, which=0, labels=False, distances=True)
         flag = None
         if st.iter >= 1 and st.same_counts:
             # labels can only equal the previous iteration's if no cluster changed size
-            prev, _, _ = self.assign(which=1, labels=True)
+            lab, _, _ = self._assign_on(xs, which=0, labels=True)
+            prev, _, _ = self._assign_on(xs, which=1, labels=True)
+            lb = 1 if self.k <= 256 else 2
             flag = torch.empty(1, dtype=torch.int32, device=self.dev)
             nat.check(self.L.nnc_labels_equal(lab.data_ptr(), prev.data_ptr(), self.n, lb, flag.data_ptr(), self.stream))
             if self.group is not None:
                 import torch.distributed as dist
 
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        base = 0
-        if self.group is not None:
-            import torch.distributed as dist
-            from . import sharding
-
-            base, _ = sharding.shard_bounds(self.n_total, dist.get_world_size(self.group), dist.get_rank(self.group))
-        keys, _ = self._farthest(d, n_empty, base)
-        delta = torch.zeros(2 * self.k, dtype=torch.int64, device=self.dev)
-        nat.check(self.L.nnc_kmeans_relocate(self.ws.data_ptr(), keys.data_ptr(), int(keys.numel()), self.x.data_ptr(),
-                                             lab.data_ptr(), lb, int(base), self.n, delta.data_ptr(), self.stream))
+        keys = self._top_keys(d, xs, n_empty)
         if self.group is not None:
             import torch.distributed as dist
 
-            dist.all_reduce(delta, op=dist.ReduceOp.SUM, group=self.group)
-        self.partials += delta
+            world = dist.get_world_size(self.group)
+            pad = torch.full((n_empty,), -1, dtype=torch.int64, device=self.dev)
+            pad[: keys.numel()] = keys
+            bufs = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad, group=self.group)
+            allk = torch.sort(torch.cat(bufs), descending=True).values
+            keys = allk[: min(n_empty, self.n_total)].contiguous()
+        nat.check(self.L.nnc_kmeans_relocate(self.ws.data_ptr(), keys.data_ptr(), int(keys.numel()), self.stream))
         nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 1, self.stream))
         if flag is not None:
             nat.check(self.L.nnc_kmeans_set_done_if(self.ws.data_ptr(), flag.data_ptr(), 3, self.stream))
         self.n_relocations += 1
-        self._reloc_labels = lab  # the labels of this iteration, kept in case it was the last (strict stop)
 
     # -------------------------------------------------------------- the fit loop
     def fit(self, want_values: bool = True):
@@ -289,7 +283,9 @@ class DeviceKMeans:
                 self._relocate_and_resume(st)
                 st = self.status()
                 if int(st.done) == 3:
-                    strict_labels = self._reloc_labels
+                    # strict stop: keep the labels of that iteration = E-step on the centres it
+                    # started from, which the resumed finalize has just made the "previous" set
+                    strict_labels = self.assign(which=1, labels=True)[0]
                 batch = 1
                 hist = []
             else:

@@ -318,9 +318,10 @@ def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True):
             # scikit-learn: whatever order numpy.argpartition leaves the top n_empty indices in
             far = np.argpartition(d, -n_empty)[: -n_empty - 1 : -1].astype(np.int32)
         else:
-            # mode B (the device rule): descending distance, equal distances by descending index.
-            # Same set of samples; same pairing as scikit-learn whenever n_empty == 1.
-            far = np.lexsort((np.arange(d.size), d))[::-1][:n_empty].astype(np.int32)
+            # mode B (the device rule): descending distance, equal distances by descending value
+            # (samples equal in both are interchangeable).  Same set of samples up to ties at the
+            # cut; same pairing as scikit-learn whenever n_empty == 1.
+            far = np.lexsort((np.arange(d.size), xc, d))[::-1][:n_empty].astype(np.int32)
         if np.max(d) != 0:
             for idx in range(n_empty):
                 new, far_idx = int(empty[idx]), int(far[idx])

@@ -358,10 +358,11 @@ def test_full_size_25m_k256_properties(nnc):
 
 
 def test_farthest_selection_rule(nnc):
-    """The device selection equals 'descending distance, ties by descending index' on crowded and
+    """The device selection equals 'descending distance, ties by descending value' on crowded and
     sparse distance distributions (it refines the histogram inside the cut bin when needed)."""
     rng = np.random.RandomState(5)
     n = 3_000_000
+    x = rng.randn(n).astype(np.float32)
     cases = {
         "uniform": rng.rand(n).astype(np.float32) * 1e-6,
         "ties": np.round(rng.rand(n) * 50).astype(np.float32) * 1e-3,
@@ -369,9 +370,13 @@ def test_farthest_selection_rule(nnc):
     }
     init = np.linspace(-1, 1, 8).astype(np.float32)
     km = nnc.kmeans.DeviceKMeans(dev(nnc, rng.rand(n).astype(np.float32)), init)
+    xd = dev(nnc, x)
     for name, d in cases.items():
         for m in (1, 7, 150):
-            keys = km._local_top_keys(dev(nnc, d), m, 0).cpu().numpy()
-            idx = keys & 0xFFFFFFFF
-            want = np.lexsort((np.arange(n), d))[::-1][:m]
-            assert np.array_equal(idx, want), (name, m)
+            keys = km._top_keys(dev(nnc, d), xd, m).cpu().numpy()
+            order = np.lexsort((x, d))[::-1][:m]
+            got_d = (keys >> 32).astype(np.uint32).view(np.float32)
+            lo = (keys & 0xFFFFFFFF).astype(np.uint32)
+            got_x = np.where(lo & 0x80000000, lo & 0x7FFFFFFF, ~lo).astype(np.uint32).view(np.float32)
+            assert np.array_equal(got_d, d[order]), (name, m)
+            assert np.array_equal(got_x, x[order]), (name, m)
