@@ -1032,7 +1032,10 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
     __syncthreads();
     if (tid == 0) { hp->start[1] = 0; hp->len[1] = n; }
     __syncthreads();
-    for (int lev = 0; lev < 7; lev++) {
+    int depth = 0; // levels with anything to split: a node of length l > 128 has children of about l/2
+    while (depth < 7 && ((n + (1 << depth) - 1) >> depth) > LEAF) depth++;
+    if (depth < 7) depth++; // rounding to multiples of 8 can push one child just over the leaf size
+    for (int lev = 0; lev < depth; lev++) {
         const int i = (1 << lev) + tid;
         if (tid < (1 << lev)) {
             const int l = hp->len[i];
@@ -1046,7 +1049,7 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
     }
     // leaves: 8 lanes per leaf (a group of 8 lanes stays together in the loop)
     const int j = tid & 7;
-    for (int node = 1 + (tid >> 3); node < 256; node += (nthr >> 3)) {
+    for (int node = 1 + (tid >> 3); node < (2 << depth) && node < 256; node += (nthr >> 3)) {
         const int l = hp->len[node];
         if (l > 0 && l <= LEAF) {
             const int st = hp->start[node];
@@ -1068,7 +1071,7 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
         }
     }
     __syncthreads();
-    for (int lev = 6; lev >= 0; lev--) {
+    for (int lev = depth - 1; lev >= 0; lev--) {
         const int i = (1 << lev) + tid;
         if (tid < (1 << lev) && hp->len[i] > LEAF) hp->val[i] = hp->val[2 * i] + hp->val[2 * i + 1];
         __syncthreads();
@@ -1102,7 +1105,6 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     __shared__ __align__(16) float cnew[NNC_KMAX];
     __shared__ float cs[NNC_KMAX];        // sorted centred centres
     __shared__ uint16_t so[NNC_KMAX];     // sorted -> original
-    __shared__ double zl[NNC_KMAX], zr[NNC_KMAX];
     __shared__ float sq[NNC_KMAX];
     __shared__ unsigned long long sh_key;
     __shared__ PwHeap heap;
@@ -1126,16 +1128,23 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     const int k = ws->p.k;
     int cur = ws->cur;
 
+    // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept its
+    // count (prev_counts); the host runs the full label comparison (strict convergence) only then.
+    // (loaded up front by original index, so that the loads overlap the shard loads)
+    const bool track = (mode == FIN_FROM_SHARDS) || (mode == FIN_FROM_PARTIALS && !resume);
+    long long pc[2] = {0, 0};
+    if (track)
+        for (int j = tid, r = 0; j < k; j += KM_THREADS, r++) pc[r] = ws->prev_counts[j];
     if (mode == FIN_FROM_SHARDS || mode == FIN_PACK_ONLY) {
         const KmTab *tab = &ws->tab[cur];
         for (int p = tid; p < k; p += KM_THREADS) {
             long long s = 0;
             unsigned long long c = 0;
+            const int o = tab->orig[p];
             for (int sh = 0; sh < KM_NSHARD; sh++) {
                 s += ws->shard_sum[sh][p]; c += ws->shard_cnt[sh][p];
                 ws->shard_sum[sh][p] = 0; ws->shard_cnt[sh][p] = 0;
             }
-            int o = tab->orig[p];
             sum_o[o] = s; cnt_o[o] = (long long)c;
             ws->partials[o] = s; ws->partials[k + o] = (long long)c;
             ws->partials_local[o] = s; ws->partials_local[k + o] = (long long)c;
@@ -1145,16 +1154,17 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         for (int j = tid; j < k; j += KM_THREADS) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
     __syncthreads();
-    FSTAMP(1);
-
-    if (mode != FIN_INIT && !resume) {
-        // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept
-        // its count; the host runs the full label comparison (strict convergence) only then.
-        int diff = 0;
-        for (int j = tid; j < k; j += KM_THREADS) { diff |= (cnt_o[j] != ws->prev_counts[j]); ws->prev_counts[j] = cnt_o[j]; }
-        const int any_diff = __syncthreads_or(diff);
+    if (track) {
+        int count_diff = 0;
+        for (int j = tid, r = 0; j < k; j += KM_THREADS, r++) {
+            const long long c = cnt_o[j];
+            count_diff |= (pc[r] != c);
+            ws->prev_counts[j] = c;
+        }
+        const int any_diff = __syncthreads_or(count_diff);
         if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
     }
+    FSTAMP(1);
 
     if (mode != FIN_INIT) {
         // ---- empty clusters?  (one barrier-with-count)
@@ -1170,14 +1180,16 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             }
             return;
         }
-        // ---- _average_centers: first index of the largest count (key = count, then lowest index)
-        for (int j = tid; j < k; j += KM_THREADS)
-            atomicMax(&sh_key, ((unsigned long long)cnt_o[j] << 11) | (unsigned long long)(2047 - j));
+        // ---- _average_centers
         const int Sft = ws->p.fix_shift;
         for (int j = tid; j < k; j += KM_THREADS)
             if (cnt_o[j] > 0) cnew[j] = (float)ldexp((double)sum_o[j] / (double)cnt_o[j], -Sft);
         __syncthreads();
         if (n_empty > 0) { // only after a relocation that bailed out (all samples on their centres)
+            // first index of the largest count (key = count, then lowest index)
+            for (int j = tid; j < k; j += KM_THREADS)
+                atomicMax(&sh_key, ((unsigned long long)cnt_o[j] << 11) | (unsigned long long)(2047 - j));
+            __syncthreads();
             const int amax = 2047 - (int)(sh_key & 2047ull);
             for (int j = tid; j < k; j += KM_THREADS)
                 if (cnt_o[j] <= 0) {
@@ -1217,7 +1229,24 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     FSTAMP(3);
     // ---- sort the centres (rank by counting; ties by original index)
     KmTab *tab = &ws->tab[cur];
-    {
+    // the centres move little per iteration: first try the previous permutation
+    int still_sorted = 0;
+    if (mode != FIN_INIT) {
+        const uint16_t *so_prev = ws->tab[cur ^ 1].orig; // the table the E-step of this iteration used
+        int ok = 1;
+        for (int p = tid; p < k; p += KM_THREADS) {
+            const int a = so_prev[p];
+            so[p] = (uint16_t)a;
+            cs[p] = cnew[a];
+            if (p + 1 < k) {
+                const int b = so_prev[p + 1];
+                const float va = cnew[a], vb = cnew[b];
+                ok &= (va < vb) || (va == vb && a < b);
+            }
+        }
+        still_sorted = __syncthreads_and(ok);
+    }
+    if (!still_sorted) {
         // rank by counting; PARTS lanes share one element and split the comparisons
         int parts = 1;
         while (parts < 64 && k * parts * 2 <= KM_THREADS) parts <<= 1;
@@ -1245,108 +1274,115 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         tab->orig[p] = so[p];
     }
     FSTAMP(4);
-    // ---- zone of every centre: the x-interval on which it can be the float32 arg-min
+    // ---- zone of every centre: the x-interval [left, right] on which it can be the float32 arg-min,
+    // turned at once into cells: cell g covers x~ - lo in [g * ra, (g+1) * rb]; centre p can open
+    // cell g iff right >= lo + g*ra  <=>  g <= G_p, and can close it iff left <= lo + (g+1)*rb  <=>
+    // g >= H_p.  G_p, H_p are rounded outwards (that only ever widens a candidate range) and made
+    // monotone (prefix max / suffix min), so that the candidate range of a cell is
+    // [first p with G_p >= g, last p with H_p <= g].
     const double U = 5.9604644775390625e-08; // 2^-24
     const double xb = fmax(fabs((double)ws->p.lo), fabs((double)ws->p.hi));
-    for (int p = tid; p < k; p += KM_THREADS) {
-        const double cp = (double)cs[p];
-        double right = INFINITY, left = -INFINITY;
-        for (int q = p + 1; q < k; q++) {
-            const double cq = (double)cs[q];
-            const double mid = 0.5 * (cp + cq);
-            if (mid >= right) break; // every later midpoint is larger still
-            const double delta = cq - cp;
-            if (delta > 0.0) {
-                const double cm = fmax(fabs(cp), fabs(cq));
-                const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                right = fmin(right, mid + E / delta);
-            }
-        }
-        for (int q = p - 1; q >= 0; q--) {
-            const double cq = (double)cs[q];
-            const double mid = 0.5 * (cp + cq);
-            if (mid <= left) break;
-            const double delta = cp - cq;
-            if (delta > 0.0) {
-                const double cm = fmax(fabs(cp), fabs(cq));
-                const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                left = fmax(left, mid - E / delta);
-            }
-        }
-        zr[p] = right; zl[p] = left;
-    }
-    __syncthreads();
-    FSTAMP(5);
-    // monotone envelopes: zr <- prefix max, zl <- suffix min.  One element per thread, k <= 1040
-    // needs two rounds of 1024; wave scan by shuffles, then the wave totals through LDS.
-    {
-        const int rounds = (k + KM_THREADS - 1) / KM_THREADS;
-        double carry_a = -INFINITY;
-        for (int rd = 0; rd < rounds; rd++) {
-            const int p = rd * KM_THREADS + tid;
-            double a = (p < k) ? zr[p] : -INFINITY;
-            for (int off = 1; off < 64; off <<= 1) {
-                const double o = __shfl_up(a, off);
-                if ((tid & 63) >= off) a = fmax(a, o);
-            }
-            if ((tid & 63) == 63) wave_a[tid >> 6] = a;
-            __syncthreads();
-            double pre = carry_a;
-            for (int w = 0; w < (tid >> 6); w++) pre = fmax(pre, wave_a[w]);
-            a = fmax(a, pre);
-            if (p < k) zr[p] = a;
-            double tot = carry_a;
-            for (int w = 0; w < KM_THREADS / 64; w++) tot = fmax(tot, wave_a[w]);
-            carry_a = tot;
-            __syncthreads();
-        }
-        double carry_b = INFINITY;
-        for (int rd = rounds - 1; rd >= 0; rd--) {
-            const int p = rd * KM_THREADS + tid;
-            double b = (p < k) ? zl[p] : INFINITY;
-            for (int off = 1; off < 64; off <<= 1) {
-                const double o = __shfl_down(b, off);
-                if ((tid & 63) + off < 64) b = fmin(b, o);
-            }
-            if ((tid & 63) == 0) wave_b[tid >> 6] = b;
-            __syncthreads();
-            double suf = carry_b;
-            for (int w = (tid >> 6) + 1; w < KM_THREADS / 64; w++) suf = fmin(suf, wave_b[w]);
-            b = fmin(b, suf);
-            if (p < k) zl[p] = b;
-            double tot = carry_b;
-            for (int w = 0; w < KM_THREADS / 64; w++) tot = fmin(tot, wave_b[w]);
-            carry_b = tot;
-            __syncthreads();
-        }
-    }
-    FSTAMP(6);
-    // ---- cells: candidate range [plo, phi] per cell.  Cell g covers x~ - lo in
-    // [g * ra, (g+1) * rb]; centre p can open cell g iff zr[p] >= lo + g*ra  <=>  g <= G_p, and can
-    // close it iff zl[p] <= lo + (g+1)*rb  <=>  g >= H_p.  G_p, H_p are rounded outwards, which
-    // only ever widens a candidate range.
     const int glog2 = ws->glog2;
     const int G = 1 << glog2;
     const double lo = (double)ws->p.lo;
     const double inv = (double)ws->inv;
     const double ra = inv > 0.0 ? (1.0 - 4.0 * U) / inv * (1.0 - 4.0 * U) : 0.0;
     const double rb = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0;
-    for (int p = tid; p < k; p += KM_THREADS) {
-        int gp = G - 1, hp_ = 0;
-        if (inv > 0.0) {
-            const double qa = (zr[p] - lo) / ra;  // may be +-inf
-            // largest g with g <= qa; the relative slack covers the rounding of the quotient
-            gp = (qa >= (double)(G - 1)) ? (G - 1) : (qa < 0.0 ? -1 : (int)(qa * (1.0 + 1e-12)));
-            if (gp > G - 1) gp = G - 1;
-            const double qb = ((zl[p] - lo) / rb - 1.0) * (1.0 - 1e-12);
-            // smallest g with g >= qb
-            if (qb <= 0.0) hp_ = 0;
-            else if (qb >= (double)G) hp_ = G;
-            else { hp_ = (int)qb; if ((double)hp_ < qb) hp_++; }
+    {
+        const int rounds = (k + KM_THREADS - 1) / KM_THREADS;
+        int *wave_i = reinterpret_cast<int *>(wave_a);
+        int carry_g = -2;
+        int gp_r[2], hp_r[2]; // k <= 1040 < 2 * KM_THREADS
+        for (int rd = 0; rd < rounds; rd++) {
+            const int p = rd * KM_THREADS + tid;
+            int gp = -2, hp_ = G + 1;
+            if (p < k) {
+                const double cp = (double)cs[p];
+                double right = INFINITY, left = -INFINITY;
+                for (int q = p + 1; q < k; q++) {
+                    const double cq = (double)cs[q];
+                    const double mid = 0.5 * (cp + cq);
+                    if (mid >= right) break; // every later midpoint is larger still
+                    const double delta = cq - cp;
+                    if (delta > 0.0) {
+                        const double cm = fmax(fabs(cp), fabs(cq));
+                        const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
+                        right = fmin(right, mid + E / delta);
+                    }
+                }
+                for (int q = p - 1; q >= 0; q--) {
+                    const double cq = (double)cs[q];
+                    const double mid = 0.5 * (cp + cq);
+                    if (mid <= left) break;
+                    const double delta = cp - cq;
+                    if (delta > 0.0) {
+                        const double cm = fmax(fabs(cp), fabs(cq));
+                        const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
+                        left = fmax(left, mid - E / delta);
+                    }
+                }
+                gp = G - 1; hp_ = 0;
+                if (inv > 0.0) {
+                    const double qa = (right - lo) / ra; // may be +-inf
+                    // largest g with g <= qa; the relative slack covers the rounding of the quotient
+                    gp = (qa >= (double)(G - 1)) ? (G - 1) : (qa < 0.0 ? -1 : (int)(qa * (1.0 + 1e-12)));
+                    if (gp > G - 1) gp = G - 1;
+                    const double qb = ((left - lo) / rb - 1.0) * (1.0 - 1e-12);
+                    // smallest g with g >= qb
+                    if (qb <= 0.0) hp_ = 0;
+                    else if (qb >= (double)G) hp_ = G;
+                    else { hp_ = (int)qb; if ((double)hp_ < qb) hp_++; }
+                }
+            }
+            gp_r[rd] = gp; hp_r[rd] = hp_;
         }
-        gcell[p] = gp; hcell[p] = hp_;
+        // prefix max of G_p
+        for (int rd = 0; rd < rounds; rd++) {
+            const int p = rd * KM_THREADS + tid;
+            int a = gp_r[rd];
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(a, off);
+                if ((tid & 63) >= off) a = max(a, o);
+            }
+            if ((tid & 63) == 63) wave_i[tid >> 6] = a;
+            __syncthreads();
+            int pre = carry_g, tot = carry_g;
+            for (int w = 0; w < KM_THREADS / 64; w++) {
+                const int wv = wave_i[w];
+                if (w < (tid >> 6)) pre = max(pre, wv);
+                tot = max(tot, wv);
+            }
+            a = max(a, pre);
+            if (p < k) gcell[p] = a;
+            carry_g = tot;
+            __syncthreads();
+        }
+        // suffix min of H_p
+        int carry_h = G + 1;
+        for (int rd = rounds - 1; rd >= 0; rd--) {
+            const int p = rd * KM_THREADS + tid;
+            int b = hp_r[rd];
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_down(b, off);
+                if ((tid & 63) + off < 64) b = min(b, o);
+            }
+            if ((tid & 63) == 0) wave_i[tid >> 6] = b;
+            __syncthreads();
+            int suf = carry_h, tot = carry_h;
+            for (int w = 0; w < KM_THREADS / 64; w++) {
+                const int wv = wave_i[w];
+                if (w > (tid >> 6)) suf = min(suf, wv);
+                tot = min(tot, wv);
+            }
+            b = min(b, suf);
+            if (p < k) hcell[p] = b;
+            carry_h = tot;
+            __syncthreads();
+        }
     }
-    __syncthreads();
+    FSTAMP(5);
+    FSTAMP(6);
+    // ---- cells
     // first and last cells are open-ended: everything below lo / above hi is clamped into them
     const int per = (G + KM_THREADS - 1) / KM_THREADS;
     const int g0 = tid * per;
