@@ -36,7 +36,7 @@ class NncError(RuntimeError):
 class KMeansParams(ctypes.Structure):
     _fields_ = [
         ("n", c_i64), ("n_total", c_i64), ("k", c_i32), ("max_iter", c_i32), ("fix_shift", c_i32),
-        ("grid_log2", c_i32), ("replicas_log2", c_i32), ("reserved", c_i32),
+        ("grid_log2", c_i32), ("replicas_log2", c_i32), ("flags", c_i32),
         ("x_mean", c_f32), ("tol", c_f32), ("lo", c_f32), ("hi", c_f32),
     ]
 

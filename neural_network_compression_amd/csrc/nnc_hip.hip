@@ -722,6 +722,8 @@ struct KmCtx {
     const uint16_t *orig_s;  // sorted position -> original index
     unsigned long long *sum_s; // [cluster][replica] fixed-point sums
     unsigned *cnt_s;           // [cluster][replica] counts
+    long long *gsum;           // DIRECT form: this workgroup's global shard (sums), NULL otherwise
+    unsigned long long *gcnt;  // DIRECT form: global shard (counts)
     float mean, lo, inv;
     int Sft, gmax, k, rlog2, rep;
 };
@@ -789,11 +791,38 @@ struct KmRun { int p; unsigned cnt; long long sum; };
 __device__ __forceinline__ void km_run_flush(const KmCtx &c, KmRun &run)
 {
     if (run.cnt) {
-        atomicAdd(&c.sum_s[(run.p << c.rlog2) + c.rep], (unsigned long long)run.sum);
-        atomicAdd(&c.cnt_s[(run.p << c.rlog2) + c.rep], run.cnt);
+        if (c.gsum) {
+            // DIRECT form (value-sorted input): a run ends a handful of times per lane per launch, so it
+            // goes straight to the global shard and the workgroup needs no LDS accumulators, no
+            // zeroing and no closing barrier
+            atomicAdd(reinterpret_cast<unsigned long long *>(&c.gsum[run.p]), (unsigned long long)run.sum);
+            atomicAdd(&c.gcnt[run.p], (unsigned long long)run.cnt);
+        } else {
+            atomicAdd(&c.sum_s[(run.p << c.rlog2) + c.rep], (unsigned long long)run.sum);
+            atomicAdd(&c.cnt_s[(run.p << c.rlog2) + c.rep], run.cnt);
+        }
     }
     run.cnt = 0;
     run.sum = 0;
+}
+
+// closing flush of the DIRECT form: the lanes of a wave usually end in the same cluster; then one
+// lane adds the wave's total
+__device__ __forceinline__ void km_run_flush_wave(const KmCtx &c, KmRun &run)
+{
+    const int p0 = __builtin_amdgcn_readfirstlane(run.p);
+    if (__all(run.p == p0 || run.cnt == 0)) {
+        long long s = run.cnt ? run.sum : 0;
+        unsigned n = run.cnt;
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); n += __shfl_down(n, off); }
+        if ((threadIdx.x & 63) == 0 && n) {
+            atomicAdd(reinterpret_cast<unsigned long long *>(&c.gsum[p0]), (unsigned long long)s);
+            atomicAdd(&c.gcnt[p0], (unsigned long long)n);
+        }
+        run.cnt = 0; run.sum = 0;
+    } else {
+        km_run_flush(c, run);
+    }
 }
 
 __device__ __forceinline__ int km_cell(const KmCtx &c, float xc)
@@ -904,26 +933,20 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
 
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
 // Work split: tiles of 2 * KM_THREADS float4 (8192 weights); tile t belongs to workgroup t mod grid.
-template <int MODE, bool VEC, typename LT, int ABL = 0>
+template <int MODE, bool VEC, typename LT, int ABL = 0, bool DIRECT = false>
 __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    if (MODE == 0 && (ws->st.done | ws->st.paused)) return;
     unsigned long long *trace = (MODE == 0) ? g_km_trace : nullptr;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (trace) tr0 = __builtin_amdgcn_s_memrealtime();
-    const int k = ws->p.k;
-    const int glog2 = ws->glog2, rlog2 = ws->rlog2;
-    const int G = 1 << glog2;
-    const int kp = (k + 7) & ~7;
-    const int t = ws->cur ^ (MODE == 1 ? (which & 1) : 0);
-    const KmTab *__restrict__ tab = &ws->tab[t];
 
     // work split: steps of KM_THREADS float4 (4096 weights); every workgroup takes a CONTIGUOUS
     // range of steps, so that on a sorted vector it stays inside a few clusters.  The first loads
-    // go out before the tables are staged, so that HBM latency overlaps the prologue.
+    // depend on the kernel arguments only and go out before anything else (the state block and the
+    // tables come from L2 while HBM is already streaming).
     const int64_t nvec = VEC ? (n >> 2) : 0;
     const int64_t nsteps = nvec / KM_THREADS;
     const int64_t per = (nsteps + gridDim.x - 1) / gridDim.x;
@@ -936,6 +959,14 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     float4 r[KM_RING];
 #pragma unroll
     for (int j = 0; j < KM_RING; j++) r[j] = ld(s0 + j);
+
+    if (MODE == 0 && (ws->st.done | ws->st.paused)) return;
+    const int k = ws->p.k;
+    const int glog2 = ws->glog2, rlog2 = ws->rlog2;
+    const int G = 1 << glog2;
+    const int kp = (k + 7) & ~7;
+    const int t = ws->cur ^ (MODE == 1 ? (which & 1) : 0);
+    const KmTab *__restrict__ tab = &ws->tab[t];
 
     uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
     float4 *pair_s = reinterpret_cast<float4 *>(smem + ((size_t)2 << glog2));
@@ -956,7 +987,7 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
             cval_s[i] = a.x;
             orig_s[i] = tab->orig[i];
         }
-        if (MODE == 0) {
+        if (MODE == 0 && !DIRECT) {
             const int tot = k << rlog2;
             for (int i = threadIdx.x; i < tot; i += KM_THREADS) { sum_s[i] = 0ull; cnt_s[i] = 0u; }
         }
@@ -968,6 +999,8 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     c.mean = ws->p.x_mean; c.lo = ws->p.lo; c.inv = ws->inv;
     c.Sft = ws->p.fix_shift; c.gmax = G - 1; c.k = k; c.rlog2 = rlog2;
     c.rep = threadIdx.x & ((1 << rlog2) - 1);
+    c.gsum = DIRECT ? ws->shard_sum[blockIdx.x & (KM_NSHARD - 1)] : nullptr;
+    c.gcnt = DIRECT ? ws->shard_cnt[blockIdx.x & (KM_NSHARD - 1)] : nullptr;
     KmRun run;
     run.p = -1; run.cnt = 0; run.sum = 0;
     if (trace) tr1 = __builtin_amdgcn_s_memrealtime();
@@ -1007,9 +1040,12 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     }
     if (trace) tr2 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0) {
-        if (ABL != 1 && ABL != 3) km_run_flush(c, run);
-        else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
-        km_flush(c, ws);
+        if (DIRECT) km_run_flush_wave(c, run);
+        else {
+            if (ABL != 1 && ABL != 3) km_run_flush(c, run);
+            else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
+            km_flush(c, ws);
+        }
     }
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = tr0; trace[4 * blockIdx.x + 1] = tr1;
@@ -1555,7 +1591,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
 {
     int glog2, rlog2;
     km_defaults(p, &glog2, &rlog2);
-    size_t lds = km_lds_bytes(p->k, glog2, rlog2, true);
+    size_t lds = km_lds_bytes(p->k, glog2, rlog2, (p->flags & 1) == 0);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     int grid = km_grid(p->n, lds);
     if (p->n == 0) return NNC_OK;
@@ -1566,7 +1602,9 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
     hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
 #define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr)
-    if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
+    const bool direct = (p->flags & 1) != 0; // caller promises long runs of equal cluster index (value-sorted input)
+    if (vec && direct && g_ablation == 0) KM_LAUNCH_ACC(true, uint8_t, 0, true);
+    else if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
     else if (vec && g_ablation == 2) KM_LAUNCH_ACC(true, uint8_t, 2);
     else if (vec && g_ablation == 3) KM_LAUNCH_ACC(true, uint8_t, 3);
     else if (vec) KM_LAUNCH_ACC(true, uint8_t);
@@ -1584,6 +1622,7 @@ static int km_set_lds_attr()
     const int maxlds = 160 * 1024;
 #define SETATTR(fn) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds))
     SETATTR((k_assign<0, true, uint8_t>));
+    SETATTR((k_assign<0, true, uint8_t, 0, true>));
     SETATTR((k_assign<0, true, uint8_t, 1>));
     SETATTR((k_assign<0, true, uint8_t, 2>));
     SETATTR((k_assign<0, true, uint8_t, 3>));

@@ -113,7 +113,7 @@ class DeviceKMeans:
         self.fix_shift = ops.fix_shift(absmax, n_total)
 
         self.p = nat.KMeansParams(n=n, n_total=n_total, k=self.k, max_iter=int(max_iter), fix_shift=self.fix_shift,
-                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), reserved=0,
+                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=0,
                                   x_mean=float(mean), tol=float(self.tol_), lo=float(lo), hi=float(hi))
         self.ws_bytes = self.L.nnc_kmeans_workspace_bytes(self.k)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
@@ -133,6 +133,8 @@ class DeviceKMeans:
         if sort is None:
             sort = n >= SORT_MIN_WEIGHTS
         self.x_iter = self._sorted_copy(x) if (sort and n > 0) else x
+        # (params.flags bit 0 selects a kernel form that flushes runs straight to global atomics; measured
+        #  6x slower: inside the cells that hold a cluster boundary the index alternates per weight)
 
     def _sorted_copy(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(x)
