@@ -628,7 +628,9 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 #define KM_THREADS 1024
 #define KM_NSHARD 8
 #define KM_GMAX 32768
-#define KM_CNT_SAT 63
+#define KM_CNT_SAT 31
+#define KM_P_BITS 11 // cell entry: first candidate (sorted position, < 2048) | min(count-1, 31) << 11
+#define KM_P_MASK 2047u
 #ifndef KM_RING
 #define KM_RING 4 // float4 loads kept in flight per thread
 #endif
@@ -636,7 +638,7 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 struct KmTab {
     float2 cand[NNC_KMAX];   // sorted: (c~, fl(c~*c~))
     uint16_t orig[NNC_KMAX]; // sorted position -> original centroid index
-    uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 63) << 10)
+    uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 31) << 11)
 };
 
 struct KmWs {
@@ -716,7 +718,7 @@ __device__ unsigned long long *g_fin_trace = nullptr; // diagnostic: phase times
 __device__ unsigned long long *g_km_trace = nullptr; // diagnostic: per-workgroup {t_start, t_loop, t_epilogue, t_end} in 100 MHz ticks
 
 struct KmCtx {
-    const uint16_t *cell_s;  // u16[G]: p_lo | (min(cnt-1, 63) << 10)
+    const uint16_t *cell_s;  // u16[G]: p_lo | (min(cnt-1, 31) << 11)
     const float4 *pair_s;    // (c_p, c_p^2, c_{p+1}, c_{p+1}^2), sorted order
     const float *cval_s;     // c_p (sorted order)
     const uint16_t *orig_s;  // sorted position -> original index
@@ -761,23 +763,23 @@ __device__ __forceinline__ void km_resolve(const KmCtx &c, const float (&xv)[B],
     // the pair is needed only where a cell holds more than one candidate; every other lane reads
     // entry 0 (one address, broadcast), so the read costs no bank conflicts and no branch
 #pragma unroll
-    for (int i = 0; i < B; i++) pr[i] = c.pair_s[(e[i] >> 10) ? (e[i] & 1023) : 0];
+    for (int i = 0; i < B; i++) pr[i] = c.pair_s[(e[i] >> KM_P_BITS) ? (e[i] & KM_P_MASK) : 0];
     bool slow_any = false;
 #pragma unroll
     for (int i = 0; i < B; i++) {
-        const unsigned cn = e[i] >> 10;
+        const unsigned cn = e[i] >> KM_P_BITS;
         const float d0 = pr[i].y + (-2.0f * (xc[i] * pr[i].x));
         const float d1 = pr[i].w + (-2.0f * (xc[i] * pr[i].z));
-        p[i] = (int)(e[i] & 1023) + (int)((cn == 1) & (d1 < d0));
+        p[i] = (int)(e[i] & KM_P_MASK) + (int)((cn == 1) & (d1 < d0));
         slow_any |= (cn >= 2) | ((cn == 1) & (d1 == d0));
     }
     if (slow_any) {
 #pragma unroll
         for (int i = 0; i < B; i++) {
-            const unsigned cn = e[i] >> 10;
+            const unsigned cn = e[i] >> KM_P_BITS;
             const float d0 = pr[i].y + (-2.0f * (xc[i] * pr[i].x));
             const float d1 = pr[i].w + (-2.0f * (xc[i] * pr[i].z));
-            if (cn >= 2 || (cn == 1 && d1 == d0)) p[i] = km_find_slow(c, xc[i], (int)(e[i] & 1023), (int)cn);
+            if (cn >= 2 || (cn == 1 && d1 == d0)) p[i] = km_find_slow(c, xc[i], (int)(e[i] & KM_P_MASK), (int)cn);
         }
     }
 }
@@ -868,7 +870,7 @@ __device__ __forceinline__ void km_accumulate4(const KmCtx &c, const float4 v, K
     const float mx = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
     const unsigned el = c.cell_s[km_cell(c, mn)];
     const unsigned eh = c.cell_s[km_cell(c, mx)];
-    if (ABL == 0 && el == eh && (el >> 10) == 0) {
+    if (ABL == 0 && el == eh && (el >> KM_P_BITS) == 0) {
         const int p = (int)el;
         // |fix| <= 2^28, so four of them add up inside int32
         const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
@@ -1441,7 +1443,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             if (hi_p < lo_p) { lo_p = 0; hi_p = k - 1; }
             int c = hi_p - lo_p;
             if (c >= KM_CNT_SAT) c = KM_CNT_SAT;
-            tab->cell[g] = (uint16_t)(lo_p | (c << 10));
+            tab->cell[g] = (uint16_t)(lo_p | (c << KM_P_BITS));
         }
     }
     FSTAMP(7);
