@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--mode", default="density")
     ap.add_argument("--q", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=4_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000)
+    ap.add_argument("--dump-durations", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -158,6 +159,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     dt = float(tmax.item())
 
+    if rank == 0 and args.dump_durations:
+        print("launch durations (us):", " ".join(f"{v * 1e3:.0f}" for v in durs[: 60]), file=sys.stderr)
     if rank == 0:
         n_iter = res.model.n_iter_ if res.model is not None else 0
         # launches enqueued after convergence inside a batch return at once: drop them

@@ -631,13 +631,20 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 #define KM_CNT_SAT 31
 #define KM_P_BITS 11 // cell entry: first candidate (sorted position, < 2048) | min(count-1, 31) << 11
 #define KM_P_MASK 2047u
+#define KM_OVF_MAX 1024     // cells with a saturated count keep their exact candidate range in a side list
+#define KM_OVF_ALL 2047u    // ... or, if even that list is full, scan every centre
 #ifndef KM_RING
 #define KM_RING 4 // float4 loads kept in flight per thread
 #endif
 
 struct KmTab {
     float2 cand[NNC_KMAX];   // sorted: (c~, fl(c~*c~))
-    uint16_t orig[NNC_KMAX]; // sorted position -> original centroid index
+    uint16_t orig[NNC_KMAX]; // sorted position -> original centroid index (lowest index among equal centres)
+    uint16_t perm[NNC_KMAX]; // the full sorted permutation of all k centres (duplicates included)
+    uint32_t ovf[KM_OVF_MAX]; // crowded cells (more than 31 candidates): first | last << 16, indexed by the cell entry
+    int32_t n_ovf;
+    int32_t ku;              // number of DISTINCT centre values = entries of cand/orig; equal centres never win (ties go to the lowest index)
+    int32_t pad_[2];
     uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 31) << 11)
 };
 
@@ -698,7 +705,7 @@ static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
     if (g < 6) g = 6;
     if (g > 15) g = 15;
     // keep table + accumulators + candidates inside 156 KiB
-    while (g > 6 && ((size_t)2 << g) + (size_t)p->k * ((size_t)1 << r) * 12 + (size_t)(p->k + 8) * 22 + 64 > 156 * 1024) g--;
+    while (g > 6 && ((size_t)2 << g) + (size_t)p->k * ((size_t)1 << r) * 12 + (size_t)(p->k + 8) * 22 + KM_OVF_MAX * 4 + 64 > 156 * 1024) g--;
     *glog2 = g;
     *rlog2 = r;
 }
@@ -708,6 +715,7 @@ static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
     size_t kp = (size_t)((k + 7) & ~7);
     size_t b = ((size_t)2 << glog2) + kp * 16 + kp * 4 + kp * 2;
     b = (b + 15) & ~(size_t)15;
+    b += KM_OVF_MAX * 4;
     if (accumulate) b += (size_t)k * ((size_t)1 << rlog2) * 12;
     return b;
 }
@@ -722,6 +730,7 @@ struct KmCtx {
     const float4 *pair_s;    // (c_p, c_p^2, c_{p+1}, c_{p+1}^2), sorted order
     const float *cval_s;     // c_p (sorted order)
     const uint16_t *orig_s;  // sorted position -> original index
+    const unsigned *ovf_s;   // crowded cells: first | last << 16
     unsigned long long *sum_s; // [cluster][replica] fixed-point sums
     unsigned *cnt_s;           // [cluster][replica] counts
     long long *gsum;           // DIRECT form: this workgroup's global shard (sums), NULL otherwise
@@ -733,7 +742,10 @@ struct KmCtx {
 // three or more candidates, or an exact float32 tie between two: the general scan
 __device__ int km_find_slow(const KmCtx &c, float xc, int p, int cnt)
 {
-    if (cnt == KM_CNT_SAT) cnt = c.k - 1 - p;
+    if (cnt == KM_CNT_SAT) { // crowded cell: the entry holds an index into the side list, not a position
+        if ((unsigned)p == KM_OVF_ALL) { p = 0; cnt = c.k - 1; }
+        else { const unsigned u = c.ovf_s[p]; p = (int)(u & 0xFFFFu); cnt = (int)(u >> 16) - p; }
+    }
     float4 cc = c.pair_s[p];
     float bestd = cc.y + (-2.0f * (xc * cc.x));
     int best = p;
@@ -763,7 +775,7 @@ __device__ __forceinline__ void km_resolve(const KmCtx &c, const float (&xv)[B],
     // the pair is needed only where a cell holds more than one candidate; every other lane reads
     // entry 0 (one address, broadcast), so the read costs no bank conflicts and no branch
 #pragma unroll
-    for (int i = 0; i < B; i++) pr[i] = c.pair_s[(e[i] >> KM_P_BITS) ? (e[i] & KM_P_MASK) : 0];
+    for (int i = 0; i < B; i++) pr[i] = c.pair_s[((e[i] >> KM_P_BITS) == 1) ? (e[i] & KM_P_MASK) : 0];
     bool slow_any = false;
 #pragma unroll
     for (int i = 0; i < B; i++) {
@@ -969,12 +981,15 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     const int kp = (k + 7) & ~7;
     const int t = ws->cur ^ (MODE == 1 ? (which & 1) : 0);
     const KmTab *__restrict__ tab = &ws->tab[t];
+    const int kt = tab->ku; // distinct centres: the sorted tables hold only those
 
     uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
     float4 *pair_s = reinterpret_cast<float4 *>(smem + ((size_t)2 << glog2));
     float *cval_s = reinterpret_cast<float *>(smem + ((size_t)2 << glog2) + (size_t)kp * 16);
     uint16_t *orig_s = reinterpret_cast<uint16_t *>(smem + ((size_t)2 << glog2) + (size_t)kp * 20);
     size_t off = (((size_t)2 << glog2) + (size_t)kp * 22 + 15) & ~(size_t)15;
+    unsigned *ovf_s = reinterpret_cast<unsigned *>(smem + off);
+    off += KM_OVF_MAX * 4;
     unsigned long long *sum_s = reinterpret_cast<unsigned long long *>(smem + off);
     unsigned *cnt_s = reinterpret_cast<unsigned *>(smem + off + ((size_t)k << rlog2) * 8);
 
@@ -982,12 +997,16 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
         const uint4 *src = reinterpret_cast<const uint4 *>(tab->cell);
         uint4 *dst = reinterpret_cast<uint4 *>(cell_s);
         for (int i = threadIdx.x; i < (G >> 3); i += KM_THREADS) dst[i] = src[i];
-        for (int i = threadIdx.x; i < k; i += KM_THREADS) {
+        for (int i = threadIdx.x; i < kt; i += KM_THREADS) {
             float2 a = tab->cand[i];
-            float2 b = (i + 1 < k) ? tab->cand[i + 1] : a;
+            float2 b = (i + 1 < kt) ? tab->cand[i + 1] : a;
             pair_s[i] = make_float4(a.x, a.y, b.x, b.y);
             cval_s[i] = a.x;
             orig_s[i] = tab->orig[i];
+        }
+        {
+            const int novf = tab->n_ovf;
+            for (int i = threadIdx.x; i < novf; i += KM_THREADS) ovf_s[i] = tab->ovf[i];
         }
         if (MODE == 0 && !DIRECT) {
             const int tot = k << rlog2;
@@ -997,9 +1016,9 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     __syncthreads();
 
     KmCtx c;
-    c.cell_s = cell_s; c.pair_s = pair_s; c.cval_s = cval_s; c.orig_s = orig_s; c.sum_s = sum_s; c.cnt_s = cnt_s;
+    c.cell_s = cell_s; c.pair_s = pair_s; c.cval_s = cval_s; c.orig_s = orig_s; c.ovf_s = ovf_s; c.sum_s = sum_s; c.cnt_s = cnt_s;
     c.mean = ws->p.x_mean; c.lo = ws->p.lo; c.inv = ws->inv;
-    c.Sft = ws->p.fix_shift; c.gmax = G - 1; c.k = k; c.rlog2 = rlog2;
+    c.Sft = ws->p.fix_shift; c.gmax = G - 1; c.k = kt; c.rlog2 = rlog2;
     c.rep = threadIdx.x & ((1 << rlog2) - 1);
     c.gsum = DIRECT ? ws->shard_sum[blockIdx.x & (KM_NSHARD - 1)] : nullptr;
     c.gcnt = DIRECT ? ws->shard_cnt[blockIdx.x & (KM_NSHARD - 1)] : nullptr;
@@ -1145,8 +1164,11 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     __shared__ uint16_t so[NNC_KMAX];     // sorted -> original
     __shared__ float sq[NNC_KMAX];
     __shared__ unsigned long long sh_key;
+    __shared__ int ovf_n;
     __shared__ PwHeap heap;
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
+    __shared__ float cu[NNC_KMAX];     // distinct sorted centre values
+    __shared__ uint16_t sou[NNC_KMAX]; // their (lowest) original indices
     __shared__ double wave_a[KM_THREADS / 64], wave_b[KM_THREADS / 64];
 
     const int tid = threadIdx.x;
@@ -1175,7 +1197,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         for (int j = tid, r = 0; j < k; j += KM_THREADS, r++) pc[r] = ws->prev_counts[j];
     if (mode == FIN_FROM_SHARDS || mode == FIN_PACK_ONLY) {
         const KmTab *tab = &ws->tab[cur];
-        for (int p = tid; p < k; p += KM_THREADS) {
+        const int ku_cur = tab->ku;
+        for (int j = tid; j < k; j += KM_THREADS) { sum_o[j] = 0; cnt_o[j] = 0; } // duplicates of a centre own nothing
+        __syncthreads();
+        for (int p = tid; p < ku_cur; p += KM_THREADS) {
             long long s = 0;
             unsigned long long c = 0;
             const int o = tab->orig[p];
@@ -1184,8 +1209,11 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
                 ws->shard_sum[sh][p] = 0; ws->shard_cnt[sh][p] = 0;
             }
             sum_o[o] = s; cnt_o[o] = (long long)c;
-            ws->partials[o] = s; ws->partials[k + o] = (long long)c;
-            ws->partials_local[o] = s; ws->partials_local[k + o] = (long long)c;
+        }
+        __syncthreads();
+        for (int j = tid; j < k; j += KM_THREADS) {
+            ws->partials[j] = sum_o[j]; ws->partials[k + j] = cnt_o[j];
+            ws->partials_local[j] = sum_o[j]; ws->partials_local[k + j] = cnt_o[j];
         }
         if (mode == FIN_PACK_ONLY) return;
     } else if (mode == FIN_FROM_PARTIALS) {
@@ -1270,7 +1298,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     // the centres move little per iteration: first try the previous permutation
     int still_sorted = 0;
     if (mode != FIN_INIT) {
-        const uint16_t *so_prev = ws->tab[cur ^ 1].orig; // the table the E-step of this iteration used
+        const uint16_t *so_prev = ws->tab[cur ^ 1].perm; // the order the E-step of this iteration used
         int ok = 1;
         for (int p = tid; p < k; p += KM_THREADS) {
             const int a = so_prev[p];
@@ -1306,11 +1334,42 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         }
     }
     __syncthreads();
-    for (int p = tid; p < k; p += KM_THREADS) {
-        float v = cs[p];
-        tab->cand[p] = make_float2(v, v * v);
-        tab->orig[p] = so[p];
+    // Equal centres: the first one (lowest original index; the sort breaks ties that way) takes every
+    // tie, the others can never win.  Keep only distinct values in the search tables.
+    int ku = 0;
+    {
+        int *wave_i = reinterpret_cast<int *>(wave_a);
+        const int rounds_u = (k + KM_THREADS - 1) / KM_THREADS;
+        int carry = 0;
+        for (int rd = 0; rd < rounds_u; rd++) {
+            const int p = rd * KM_THREADS + tid;
+            float v = 0.0f;
+            int o = 0, first = 0;
+            if (p < k) {
+                v = cs[p]; o = so[p];
+                tab->perm[p] = (uint16_t)o;
+                first = (p == 0) || (cs[p - 1] != v);
+            }
+            const unsigned long long bal = __ballot(first);
+            const int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            if ((tid & 63) == 0) wave_i[tid >> 6] = __popcll(bal);
+            __syncthreads();
+            int pre = carry, tot = carry;
+            for (int w = 0; w < KM_THREADS / 64; w++) { const int wv = wave_i[w]; if (w < (tid >> 6)) pre += wv; tot += wv; }
+            if (first) { cu[pre + before] = v; sou[pre + before] = (uint16_t)o; }
+            carry = tot;
+            __syncthreads();
+        }
+        ku = carry;
     }
+    for (int p = tid; p < ku; p += KM_THREADS) {
+        const float v = cu[p];
+        cs[p] = v;
+        tab->cand[p] = make_float2(v, v * v);
+        tab->orig[p] = sou[p];
+    }
+    if (tid == 0) { tab->ku = ku; ovf_n = 0; }
+    __syncthreads();
     FSTAMP(4);
     // ---- zone of every centre: the x-interval [left, right] on which it can be the float32 arg-min,
     // turned at once into cells: cell g covers x~ - lo in [g * ra, (g+1) * rb]; centre p can open
@@ -1327,17 +1386,17 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     const double ra = inv > 0.0 ? (1.0 - 4.0 * U) / inv * (1.0 - 4.0 * U) : 0.0;
     const double rb = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0;
     {
-        const int rounds = (k + KM_THREADS - 1) / KM_THREADS;
+        const int rounds = (ku + KM_THREADS - 1) / KM_THREADS;
         int *wave_i = reinterpret_cast<int *>(wave_a);
         int carry_g = -2;
-        int gp_r[2], hp_r[2]; // k <= 1040 < 2 * KM_THREADS
+        int gp_r[2], hp_r[2]; // ku <= 1040 < 2 * KM_THREADS
         for (int rd = 0; rd < rounds; rd++) {
             const int p = rd * KM_THREADS + tid;
             int gp = -2, hp_ = G + 1;
-            if (p < k) {
+            if (p < ku) {
                 const double cp = (double)cs[p];
                 double right = INFINITY, left = -INFINITY;
-                for (int q = p + 1; q < k; q++) {
+                for (int q = p + 1; q < ku; q++) {
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
                     if (mid >= right) break; // every later midpoint is larger still
@@ -1391,7 +1450,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
                 tot = max(tot, wv);
             }
             a = max(a, pre);
-            if (p < k) gcell[p] = a;
+            if (p < ku) gcell[p] = a;
             carry_g = tot;
             __syncthreads();
         }
@@ -1413,7 +1472,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
                 tot = min(tot, wv);
             }
             b = min(b, suf);
-            if (p < k) hcell[p] = b;
+            if (p < ku) hcell[p] = b;
             carry_h = tot;
             __syncthreads();
         }
@@ -1426,26 +1485,34 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     const int g0 = tid * per;
     if (g0 < G) {
         // plo(g) = first p with G_p >= g ; phi(g) = last p with H_p <= g  (both monotone in g)
-        int l = 0, h = k - 1;
+        int l = 0, h = ku - 1;
         while (l < h) { int m = (l + h) >> 1; if (gcell[m] >= g0) h = m; else l = m + 1; }
         int plo = l;
-        l = 0; h = k - 1;
+        l = 0; h = ku - 1;
         while (l < h) { int m = (l + h + 1) >> 1; if (hcell[m] <= g0) l = m; else h = m - 1; }
         int phi = l;
         int gnext = gcell[plo];                            // plo stays while g <= gnext
-        int hnext = (phi + 1 < k) ? hcell[phi + 1] : G + 1; // phi advances once g >= hnext
+        int hnext = (phi + 1 < ku) ? hcell[phi + 1] : G + 1; // phi advances once g >= hnext
         for (int g = g0; g < g0 + per && g < G; g++) {
-            while (plo < k - 1 && gnext < g) { plo++; gnext = gcell[plo]; }
-            while (phi < k - 1 && hnext <= g) { phi++; hnext = (phi + 1 < k) ? hcell[phi + 1] : G + 1; }
+            while (plo < ku - 1 && gnext < g) { plo++; gnext = gcell[plo]; }
+            while (phi < ku - 1 && hnext <= g) { phi++; hnext = (phi + 1 < ku) ? hcell[phi + 1] : G + 1; }
             int lo_p = (g == 0) ? 0 : plo;       // below lo nothing exists, but keep cell 0 / G-1 conservative
-            int hi_p = (g == G - 1) ? k - 1 : phi;
+            int hi_p = (g == G - 1) ? ku - 1 : phi;
             if (g == 0) { lo_p = 0; }
-            if (hi_p < lo_p) { lo_p = 0; hi_p = k - 1; }
+            if (hi_p < lo_p) { lo_p = 0; hi_p = ku - 1; }
             int c = hi_p - lo_p;
-            if (c >= KM_CNT_SAT) c = KM_CNT_SAT;
-            tab->cell[g] = (uint16_t)(lo_p | (c << KM_P_BITS));
+            int field = lo_p;
+            if (c >= KM_CNT_SAT) {
+                c = KM_CNT_SAT;
+                const int idx = atomicAdd(&ovf_n, 1);
+                if (idx < KM_OVF_MAX) { tab->ovf[idx] = (unsigned)lo_p | ((unsigned)hi_p << 16); field = idx; }
+                else field = (int)KM_OVF_ALL;
+            }
+            tab->cell[g] = (uint16_t)(field | (c << KM_P_BITS));
         }
     }
+    __syncthreads();
+    if (tid == 0) tab->n_ovf = ovf_n < KM_OVF_MAX ? ovf_n : KM_OVF_MAX;
     FSTAMP(7);
 #undef FSTAMP
 }

@@ -274,7 +274,7 @@ class DeviceKMeans:
         """Runs to convergence.  Returns (QuantizedModel, values tensor or None) where
         values = cluster_centers_[labels_] as a device float32 vector (utility.py:239)."""
         strict_labels = None
-        batch = self.batch
+        batch = 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
         while True:
             self.iterate(batch)
