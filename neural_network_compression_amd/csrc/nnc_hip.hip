@@ -805,37 +805,35 @@ struct KmRun { int p; unsigned cnt; long long sum; };
 __device__ __forceinline__ void km_run_flush(const KmCtx &c, KmRun &run)
 {
     if (run.cnt) {
-        if (c.gsum) {
-            // DIRECT form (value-sorted input): a run ends a handful of times per lane per launch, so it
-            // goes straight to the global shard and the workgroup needs no LDS accumulators, no
-            // zeroing and no closing barrier
-            atomicAdd(reinterpret_cast<unsigned long long *>(&c.gsum[run.p]), (unsigned long long)run.sum);
-            atomicAdd(&c.gcnt[run.p], (unsigned long long)run.cnt);
-        } else {
-            atomicAdd(&c.sum_s[(run.p << c.rlog2) + c.rep], (unsigned long long)run.sum);
-            atomicAdd(&c.cnt_s[(run.p << c.rlog2) + c.rep], run.cnt);
-        }
+        atomicAdd(&c.sum_s[(run.p << c.rlog2) + c.rep], (unsigned long long)run.sum);
+        atomicAdd(&c.cnt_s[(run.p << c.rlog2) + c.rep], run.cnt);
     }
     run.cnt = 0;
     run.sum = 0;
 }
 
-// closing flush of the DIRECT form: the lanes of a wave usually end in the same cluster; then one
-// lane adds the wave's total
-__device__ __forceinline__ void km_run_flush_wave(const KmCtx &c, KmRun &run)
+// DIRECT form (value-sorted input): runs go to the global shard, aggregated per wave.  Called by
+// ALL lanes of a wave (wave-uniform branch); `need` marks the lanes whose run ends here.  Lanes
+// that end a run of the same cluster are summed with a butterfly and one lane adds the total, so
+// a workgroup crossing a cluster boundary issues a few global atomics, not one per lane.
+__device__ __forceinline__ void km_wave_flush(const KmCtx &c, KmRun &run, bool need)
 {
-    const int p0 = __builtin_amdgcn_readfirstlane(run.p);
-    if (__all(run.p == p0 || run.cnt == 0)) {
-        long long s = run.cnt ? run.sum : 0;
-        unsigned n = run.cnt;
-        for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); n += __shfl_down(n, off); }
-        if ((threadIdx.x & 63) == 0 && n) {
+    need = need && run.cnt != 0;
+    unsigned long long todo = __ballot(need);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int p0 = __shfl(run.p, leader);
+        const bool grp = need && run.p == p0;
+        const unsigned long long m = __ballot(grp);
+        long long s = grp ? run.sum : 0;
+        unsigned n = grp ? run.cnt : 0u;
+        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); n += __shfl_xor(n, off); }
+        if ((int)(threadIdx.x & 63) == leader) {
             atomicAdd(reinterpret_cast<unsigned long long *>(&c.gsum[p0]), (unsigned long long)s);
             atomicAdd(&c.gcnt[p0], (unsigned long long)n);
         }
-        run.cnt = 0; run.sum = 0;
-    } else {
-        km_run_flush(c, run);
+        if (grp) { run.cnt = 0; run.sum = 0; }
+        todo &= ~m;
     }
 }
 
@@ -874,24 +872,55 @@ __device__ __forceinline__ void km_accumulate(const KmCtx &c, const float (&xv)[
 // of the four hold the same single candidate, every cell between them does too (the candidate
 // ranges are monotone in the cell index), so all four weights belong to that cluster: two table
 // reads and no distance arithmetic.  On a value-sorted vector nearly every float4 takes it.
-template <int ABL>
-__device__ __forceinline__ void km_accumulate4(const KmCtx &c, const float4 v, KmRun &run)
+template <int ABL, bool DIRECT>
+__device__ __forceinline__ void km_accumulate4(const KmCtx &c, const float4 v, KmRun &run, const int nvalid = 4)
 {
     const float x0 = v.x - c.mean, x1 = v.y - c.mean, x2 = v.z - c.mean, x3 = v.w - c.mean;
     const float mn = fminf(fminf(x0, x1), fminf(x2, x3));
     const float mx = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
     const unsigned el = c.cell_s[km_cell(c, mn)];
     const unsigned eh = c.cell_s[km_cell(c, mx)];
-    if (ABL == 0 && el == eh && (el >> KM_P_BITS) == 0) {
-        const int p = (int)el;
-        // |fix| <= 2^28, so four of them add up inside int32
-        const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
-        if (p != run.p) { km_run_flush(c, run); run.p = p; }
-        run.cnt += 4;
-        run.sum += q;
+    if (!DIRECT) {
+        if (ABL == 0 && el == eh && (el >> KM_P_BITS) == 0) {
+            const int p = (int)el;
+            // |fix| <= 2^28, so four of them add up inside int32
+            const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
+            if (p != run.p) { km_run_flush(c, run); run.p = p; }
+            run.cnt += 4;
+            run.sum += q;
+        } else {
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            km_accumulate<4, ABL>(c, xv, run);
+        }
     } else {
-        const float xv[4] = {v.x, v.y, v.z, v.w};
-        km_accumulate<4, ABL>(c, xv, run);
+        // Common case: the whole float4 of a lane belongs to one cluster -> one vote per float4.
+        // Lanes whose float4 straddles a boundary (or sits in a multi-candidate cell) are handled
+        // element by element in a second, wave-uniform section.
+        const bool full = nvalid == 4;
+        const bool uniform4 = full && (el == eh) && ((el >> KM_P_BITS) == 0);
+        {
+            const int p = (int)(el & KM_P_MASK);
+            const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
+            const bool need = uniform4 && (p != run.p);
+            if (__any(need)) km_wave_flush(c, run, need);
+            if (uniform4) { run.p = p; run.cnt += 4; run.sum += q; }
+        }
+        if (__any(!uniform4 && nvalid > 0)) {
+            int p[4] = {0, 0, 0, 0};
+            if (!uniform4 && nvalid > 0) {
+                const float xv[4] = {v.x, v.y, v.z, v.w};
+                float xc[4];
+                km_resolve<4>(c, xv, xc, p);
+            }
+            const int q[4] = {fix_f32(x0, c.Sft), fix_f32(x1, c.Sft), fix_f32(x2, c.Sft), fix_f32(x3, c.Sft)};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool have = !uniform4 && i < nvalid;
+                const bool need = have && (p[i] != run.p);
+                if (__any(need)) km_wave_flush(c, run, need);
+                if (have) { run.p = p[i]; run.cnt += 1; run.sum += q[i]; }
+            }
+        }
     }
 }
 
@@ -948,7 +977,7 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
 // Work split: tiles of 2 * KM_THREADS float4 (8192 weights); tile t belongs to workgroup t mod grid.
 template <int MODE, bool VEC, typename LT, int ABL = 0, bool DIRECT = false>
-__global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
+__global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out)
 {
@@ -1034,7 +1063,7 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
                 const float4 v = r[j];
                 r[j] = ld(cur + KM_RING);
                 if (cur < s1) {
-                    if (MODE == 0) km_accumulate4<ABL>(c, v, run);
+                    if (MODE == 0) km_accumulate4<ABL, DIRECT>(c, v, run);
                     else {
                         const float xa[4] = {v.x, v.y, v.z, v.w};
                         km_emit<4, LT>(c, xa, 4 * (cur * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out);
@@ -1043,25 +1072,44 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
             }
         }
     }
-    // ragged end (less than one tile of float4s, then the scalars): last workgroup
+    // ragged end (less than one step of float4s, then the scalars): last workgroup
     if (blockIdx.x == gridDim.x - 1) {
         const int64_t vdone = nsteps * KM_THREADS;
-        for (int64_t v = vdone + threadIdx.x; v < nvec; v += KM_THREADS) {
-            const float4 a4 = x4[v];
-            const float xa[4] = {a4.x, a4.y, a4.z, a4.w};
-            if (MODE == 0) km_accumulate4<ABL>(c, a4, run);
-            else km_emit<4, LT>(c, xa, 4 * v, labels_out, quant_out, dist_out);
-        }
-        // scalars: fewer than 4 when the input is 16-byte aligned; the whole vector otherwise
-        for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += KM_THREADS) {
-            const float xs[1] = {x[i]};
-            if (MODE == 0) km_accumulate<1, ABL>(c, xs, run);
-            else km_emit<1, LT>(c, xs, i, labels_out, quant_out, dist_out);
+        if (MODE == 0 && DIRECT) {
+            // every lane runs every round (the flush votes are wave-wide); lanes past the end carry no element
+            const int64_t vrounds = (nvec - vdone + KM_THREADS - 1) / KM_THREADS;
+            for (int64_t r = 0; r < vrounds; r++) {
+                const int64_t v = vdone + r * KM_THREADS + threadIdx.x;
+                const bool have = v < nvec;
+                const float4 a4 = have ? x4[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+                km_accumulate4<ABL, DIRECT>(c, a4, run, have ? 4 : 0);
+            }
+            const int64_t sbase = nvec << 2;
+            const int64_t srounds = (n - sbase + KM_THREADS - 1) / KM_THREADS;
+            for (int64_t r = 0; r < srounds; r++) {
+                const int64_t i = sbase + r * KM_THREADS + threadIdx.x;
+                const bool have = i < n;
+                const float xv = have ? x[i] : 0.0f;
+                km_accumulate4<ABL, DIRECT>(c, make_float4(xv, xv, xv, xv), run, have ? 1 : 0);
+            }
+        } else {
+            for (int64_t v = vdone + threadIdx.x; v < nvec; v += KM_THREADS) {
+                const float4 a4 = x4[v];
+                const float xa[4] = {a4.x, a4.y, a4.z, a4.w};
+                if (MODE == 0) km_accumulate4<ABL, DIRECT>(c, a4, run);
+                else km_emit<4, LT>(c, xa, 4 * v, labels_out, quant_out, dist_out);
+            }
+            // scalars: fewer than 4 when the input is 16-byte aligned; the whole vector otherwise
+            for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += KM_THREADS) {
+                const float xs[1] = {x[i]};
+                if (MODE == 0) km_accumulate<1, ABL>(c, xs, run);
+                else km_emit<1, LT>(c, xs, i, labels_out, quant_out, dist_out);
+            }
         }
     }
     if (trace) tr2 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0) {
-        if (DIRECT) km_run_flush_wave(c, run);
+        if (DIRECT) km_wave_flush(c, run, true);
         else {
             if (ABL != 1 && ABL != 3) km_run_flush(c, run);
             else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
@@ -1568,11 +1616,12 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     return NNC_OK;
 }
 
-static int km_grid(int64_t n, size_t lds_bytes)
+static int km_grid(int64_t n, size_t lds_bytes, bool one_per_cu = false)
 {
     int64_t blocks = ((n + 7) / 8 + KM_THREADS - 1) / KM_THREADS;
     if (blocks < 1) blocks = 1;
     int per_cu = (lds_bytes + 1024 <= 80 * 1024) ? 2 : 1; // two 1024-thread workgroups fit a CU if LDS allows
+    if (one_per_cu) per_cu = 1;                            // ... and registers (the DIRECT form needs more than 64)
     static int mult_q = -1; // tuning knob: workgroups per resident slot, in quarters (NNC_KM_GRID_QUARTERS)
     if (mult_q < 0) { const char *e = getenv("NNC_KM_GRID_QUARTERS"); mult_q = e ? atoi(e) : 4; if (mult_q < 1) mult_q = 4; }
     return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu * mult_q / 4);
@@ -1662,7 +1711,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     km_defaults(p, &glog2, &rlog2);
     size_t lds = km_lds_bytes(p->k, glog2, rlog2, (p->flags & 1) == 0);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    int grid = km_grid(p->n, lds);
+    int grid = km_grid(p->n, lds, vec && (p->flags & 1) != 0 && g_ablation == 0);
     if (p->n == 0) return NNC_OK;
     const bool prof = g_prof_on && g_prof_used < g_prof_pool.size();
     if (g_prof_on && !prof) g_prof_skipped++;

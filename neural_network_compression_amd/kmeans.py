@@ -133,8 +133,9 @@ class DeviceKMeans:
         if sort is None:
             sort = n >= SORT_MIN_WEIGHTS
         self.x_iter = self._sorted_copy(x) if (sort and n > 0) else x
-        # (params.flags bit 0 selects a kernel form that flushes runs straight to global atomics; measured
-        #  6x slower: inside the cells that hold a cluster boundary the index alternates per weight)
+        # params.flags bit 0 selects the DIRECT kernel form (runs flushed per wave straight to global atomics,
+        # no LDS accumulators, no closing barrier).  Measured slower end to end: it needs > 64 VGPRs (one
+        # workgroup per CU) and, on pruned tensors, thousands of waves end on the zero cluster's address.
 
     def _sorted_copy(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(x)
