@@ -14,7 +14,8 @@ from oracle import oracle as orc  # noqa: E402
 @pytest.fixture(scope="module")
 def km_mod():
     assert torch.cuda.is_available()
-    from neural_network_compression_amd import _native, kmeans, ops
+    from neural_network_compression_amd import _native, build as _b, kmeans, ops
+    _b.build_native()  # no-op when csrc/libnnc_hip.so is up to date
     _native.load()
     return kmeans, ops
 

@@ -32,6 +32,8 @@ def nnc():
     from neural_network_compression_amd import _native, kmeans, ops
     from neural_network_compression_amd.common import utility
 
+    from neural_network_compression_amd import build as _b
+    _b.build_native()  # no-op when csrc/libnnc_hip.so is up to date
     _native.load()  # fails loudly if the HIP library is missing
 
     class NS:

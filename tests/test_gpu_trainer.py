@@ -16,7 +16,8 @@ from oracle import oracle as orc  # noqa: E402
 @pytest.fixture(scope="module")
 def trainer_mod():
     assert torch.cuda.is_available()
-    from neural_network_compression_amd import _native
+    from neural_network_compression_amd import _native, build as _b
+    _b.build_native()  # no-op when csrc/libnnc_hip.so is up to date
     _native.load()
     from neural_network_compression_amd import le_net_300_100_trainer, main, pipeline
     from neural_network_compression_amd.common import trainer
