@@ -186,9 +186,11 @@ int nnc_kmeans_get_centers(void *ws, int which, int centred, float *out_dev, voi
  * any of the outputs may be NULL.
  *   labels_out : centroid index per element, uint8 if label_bytes == 1 (k <= 256) else uint16
  *   quant_out  : cluster_centers_[labels_] (un-centred float32 centre values), utility.py:239
- *   dist_out   : (x~ - c~[label])^2 in float32, the distances _relocate_empty_clusters needs */
+ *   dist_out   : (x~ - c~[label])^2 in float32, the distances _relocate_empty_clusters needs
+ *   dist_hist4096_dev : with dist_out, also the 4096-bin histogram of (bits(dist) >> 19) & 4095
+ *                (zeroed here): the first level of nnc_topm_hist_f32, for free in the same pass */
 int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int which, void *labels_out,
-                      int label_bytes, float *quant_out, float *dist_out, void *stream);
+                      int label_bytes, float *quant_out, float *dist_out, int64_t *dist_hist4096_dev, void *stream);
 
 /* Selection of the farthest samples for scikit-learn's empty-cluster relocation
  * (_k_means_common.pyx:167-211: np.argpartition(distances, -n_empty)), on the device (d >= 0, so the

@@ -940,9 +940,19 @@ __device__ __forceinline__ void km_flush(const KmCtx &c, KmWs *ws)
     }
 }
 
+struct KmHistRun { unsigned bin, cnt; };
+
+__device__ __forceinline__ void km_hist_add(unsigned *hist_s, KmHistRun &hr, float d)
+{
+    const unsigned b = (__float_as_uint(d) >> 19) & 4095u; // top 12 value bits of a non-negative float
+    if (b != hr.bin) { if (hr.cnt) atomicAdd(&hist_s[hr.bin], hr.cnt); hr.bin = b; hr.cnt = 0; }
+    hr.cnt++;
+}
+
 template <int B, typename LT>
 __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], int64_t i0, LT *__restrict__ labels_out,
-                                        float *__restrict__ quant_out, float *__restrict__ dist_out)
+                                        float *__restrict__ quant_out, float *__restrict__ dist_out,
+                                        unsigned *hist_s, KmHistRun &hr)
 {
     float xc[B];
     int p[B];
@@ -956,6 +966,7 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
         qv[i] = cv + c.mean;
         const float dd = xc[i] - cv;
         dv[i] = dd * dd;
+        if (hist_s) km_hist_add(hist_s, hr, dv[i]);
     }
     if (B == 4) {
         if (labels_out) {
@@ -979,7 +990,8 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
 template <int MODE, bool VEC, typename LT, int ABL = 0, bool DIRECT = false>
 __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
-                                                       float *__restrict__ quant_out, float *__restrict__ dist_out)
+                                                       float *__restrict__ quant_out, float *__restrict__ dist_out,
+                                                       unsigned long long *__restrict__ dist_hist = nullptr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned long long *trace = (MODE == 0) ? g_km_trace : nullptr;
@@ -1041,8 +1053,15 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
             const int tot = k << rlog2;
             for (int i = threadIdx.x; i < tot; i += KM_THREADS) { sum_s[i] = 0ull; cnt_s[i] = 0u; }
         }
+        if (MODE == 1 && dist_hist) {
+            unsigned *hz = reinterpret_cast<unsigned *>(sum_s); // label mode has no accumulators: the space holds the histogram
+            for (int i = threadIdx.x; i < 4096; i += KM_THREADS) hz[i] = 0u;
+        }
     }
     __syncthreads();
+    unsigned *hist_s = (MODE == 1 && dist_hist) ? reinterpret_cast<unsigned *>(sum_s) : nullptr;
+    KmHistRun hr;
+    hr.bin = 0xFFFFFFFFu; hr.cnt = 0;
 
     KmCtx c;
     c.cell_s = cell_s; c.pair_s = pair_s; c.cval_s = cval_s; c.orig_s = orig_s; c.ovf_s = ovf_s; c.sum_s = sum_s; c.cnt_s = cnt_s;
@@ -1066,7 +1085,7 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
                     if (MODE == 0) km_accumulate4<ABL, DIRECT>(c, v, run);
                     else {
                         const float xa[4] = {v.x, v.y, v.z, v.w};
-                        km_emit<4, LT>(c, xa, 4 * (cur * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out);
+                        km_emit<4, LT>(c, xa, 4 * (cur * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out, hist_s, hr);
                     }
                 }
             }
@@ -1097,13 +1116,13 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
                 const float4 a4 = x4[v];
                 const float xa[4] = {a4.x, a4.y, a4.z, a4.w};
                 if (MODE == 0) km_accumulate4<ABL, DIRECT>(c, a4, run);
-                else km_emit<4, LT>(c, xa, 4 * v, labels_out, quant_out, dist_out);
+                else km_emit<4, LT>(c, xa, 4 * v, labels_out, quant_out, dist_out, hist_s, hr);
             }
             // scalars: fewer than 4 when the input is 16-byte aligned; the whole vector otherwise
             for (int64_t i = (nvec << 2) + threadIdx.x; i < n; i += KM_THREADS) {
                 const float xs[1] = {x[i]};
                 if (MODE == 0) km_accumulate<1, ABL>(c, xs, run);
-                else km_emit<1, LT>(c, xs, i, labels_out, quant_out, dist_out);
+                else km_emit<1, LT>(c, xs, i, labels_out, quant_out, dist_out, hist_s, hr);
             }
         }
     }
@@ -1115,6 +1134,12 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
             else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
             km_flush(c, ws);
         }
+    }
+    if (MODE == 1 && hist_s) {
+        if (hr.cnt) atomicAdd(&hist_s[hr.bin], hr.cnt);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 4096; i += KM_THREADS)
+            if (hist_s[i]) atomicAdd(&dist_hist[i], (unsigned long long)hist_s[i]);
     }
     if (trace && threadIdx.x == 0) {
         trace[4 * blockIdx.x + 0] = tr0; trace[4 * blockIdx.x + 1] = tr1;
@@ -1719,7 +1744,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     // command processor's arrival), so the difference is the launch's execution time
     hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
     hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
-#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr)
+#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr)
     const bool direct = (p->flags & 1) != 0; // caller promises long runs of equal cluster index (value-sorted input)
     if (vec && direct && g_ablation == 0) KM_LAUNCH_ACC(true, uint8_t, 0, true);
     else if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
@@ -1833,7 +1858,8 @@ extern "C" int nnc_kmeans_get_centers(void *ws, int which, int centred, float *o
 }
 
 extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int which, void *labels_out,
-                                 int label_bytes, float *quant_out, float *dist_out, void *stream)
+                                 int label_bytes, float *quant_out, float *dist_out, int64_t *dist_hist4096_dev,
+                                 void *stream)
 {
     int rc = km_check(ws, pp, "nnc_kmeans_assign");
     if (rc) return rc;
@@ -1845,16 +1871,19 @@ extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_para
     if ((rc = km_set_lds_attr())) return rc;
     int glog2, rlog2;
     km_defaults(&p, &glog2, &rlog2);
-    size_t lds = km_lds_bytes(p.k, glog2, rlog2, false);
+    if (dist_hist4096_dev && !dist_out) return fail(NNC_EINVAL, "nnc_kmeans_assign: the distance histogram needs dist_out");
+    size_t lds = km_lds_bytes(p.k, glog2, rlog2, false) + (dist_hist4096_dev ? 4096 * sizeof(unsigned) : 0);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     int grid = km_grid(p.n, lds);
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+    unsigned long long *dh = reinterpret_cast<unsigned long long *>(dist_hist4096_dev);
+    if (dh) HIPCHK(hipMemsetAsync(dh, 0, 4096 * sizeof(int64_t), S(stream)));
     if (label_bytes == 2) {
-        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out);
-        else hipLaunchKernelGGL((k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out);
+        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh);
+        else hipLaunchKernelGGL((k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh);
     } else {
-        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out);
-        else hipLaunchKernelGGL((k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out);
+        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh);
+        else hipLaunchKernelGGL((k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh);
     }
     LAUNCHCHK("k_assign<labels>");
     return NNC_OK;

@@ -167,7 +167,7 @@ class DeviceKMeans:
         return self._assign_on(self.x, which, labels, values, distances)
 
     def _assign_on(self, src: torch.Tensor, which: int = 0, labels: bool = True, values: bool = False,
-                   distances: bool = False):
+                   distances: bool = False, dist_hist: torch.Tensor | None = None):
         lab = q = d = None
         lb = 1 if self.k <= 256 else 2
         if labels:
@@ -177,7 +177,7 @@ class DeviceKMeans:
         if distances:
             d = torch.empty(self.n, dtype=torch.float32, device=self.dev)
         nat.check(self.L.nnc_kmeans_assign(src.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(which),
-                                           ops._ptr(lab), lb, ops._ptr(q), ops._ptr(d), self.stream))
+                                           ops._ptr(lab), lb, ops._ptr(q), ops._ptr(d), ops._ptr(dist_hist), self.stream))
         return lab, q, d
 
     def centers(self, which: int = 0, centred: bool = False) -> np.ndarray:
@@ -188,7 +188,7 @@ class DeviceKMeans:
     # -------------------------------------------------------------- empty-cluster relocation
     TOPM_CAP = 1 << 16
 
-    def _top_keys(self, d: torch.Tensor, x: torch.Tensor, m: int) -> torch.Tensor:
+    def _top_keys(self, d: torch.Tensor, x: torch.Tensor, m: int, hist0: torch.Tensor | None = None) -> torch.Tensor:
         """Keys of the m samples farthest from their own centre (this shard), descending.  A key is
         (float32 bits of d) << 32 | order-preserving bits of x: descending keys = descending
         distance, equal distances by descending value; samples equal in both are interchangeable,
@@ -199,11 +199,12 @@ class DeviceKMeans:
         m = min(m, n)
         if m == 0:
             return torch.empty(0, dtype=torch.int64, device=self.dev)
-        hist = torch.empty(4096, dtype=torch.int64, device=self.dev)
+        hist = hist0 if hist0 is not None else torch.empty(4096, dtype=torch.int64, device=self.dev)
         prefix, decided, thr_bits, cand = None, 0, 0, n
         for shift, width, pshift in ((19, 12, -1), (7, 12, 19), (0, 7, 7)):   # 12 + 12 + 7 value bits (sign bit is 0)
-            nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, shift, width, pshift, 0 if prefix is None else prefix,
-                                               hist.data_ptr(), self.stream))
+            if not (shift == 19 and hist0 is not None):  # the first level may come for free from the distance pass
+                nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, shift, width, pshift, 0 if prefix is None else prefix,
+                                                   hist.data_ptr(), self.stream))
             self._hist_pin.copy_(hist, non_blocking=True)
             torch.cuda.current_stream(self.dev).synchronize()
             h = self._hist_pin.numpy()
@@ -240,7 +241,8 @@ class DeviceKMeans:
         defined (CPU-dispatch dependent) pairing otherwise."""
         n_empty = int(st.n_empty)
         xs = self.x_iter  # any order will do; the value-sorted copy makes the histogram cheap
-        _, _, d = self._assign_on(xs, which=0, labels=False, distances=True)
+        hist0 = torch.empty(4096, dtype=torch.int64, device=self.dev)
+        _, _, d = self._assign_on(xs, which=0, labels=False, distances=True, dist_hist=hist0)
         flag = None
         if st.iter >= 1 and st.same_counts:
             # labels can only equal the previous iteration's if no cluster changed size
@@ -253,7 +255,7 @@ class DeviceKMeans:
                 import torch.distributed as dist
 
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        keys = self._top_keys(d, xs, n_empty)
+        keys = self._top_keys(d, xs, n_empty, hist0)
         if self.group is not None:
             import torch.distributed as dist
 
