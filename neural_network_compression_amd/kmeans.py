@@ -282,29 +282,29 @@ class DeviceKMeans:
         while True:
             self.iterate(batch)
             st = self.status()
-            if st.paused:
-                # an empty cluster stopped the device loop inside this batch: relocate, resume
-                # that iteration, then go on one iteration at a time for a while
-                self._relocate_and_resume(st)
-                st = self.status()
-                if int(st.done) == 3:
-                    # strict stop: keep the labels of that iteration = E-step on the centres it
-                    # started from, which the resumed finalize has just made the "previous" set
-                    strict_labels = self.assign(which=1, labels=True)[0]
-                batch = 1
-                hist = []
-            else:
-                # size the next batch so that it ends about where the shift crosses the tolerance
-                # (launches enqueued after convergence are no-ops, but they still cost a dispatch)
-                hist.append((int(st.iter), float(st.shift_tot)))
-                batch = min(self.batch, batch * 2)
-                if len(hist) >= 2 and hist[-1][1] > 0 and hist[-2][1] > hist[-1][1] and self.tol_ > 0:
-                    (i0, s0), (i1, s1) = hist[-2], hist[-1]
-                    rate = math.log(s0 / s1) / max(1, i1 - i0)          # log-decay per iteration
-                    left = math.log(s1 / float(self.tol_)) / rate if s1 > float(self.tol_) else 0.0
-                    batch = int(max(1, min(self.batch, math.floor(left * 0.9))))
             if st.done:
                 break
+            if st.paused:
+                # an empty cluster stopped the device loop inside this batch: relocate and resume that
+                # iteration on the device, then go on one iteration at a time for a while.  No look-in
+                # in between: if the resumed iteration was the last one the next launch is a no-op.
+                self._relocate_and_resume(st)
+                batch = 1
+                hist = []
+                continue
+            # size the next batch so that it ends about where the shift crosses the tolerance
+            # (launches enqueued after convergence are no-ops, but they still cost a dispatch)
+            hist.append((int(st.iter), float(st.shift_tot)))
+            batch = min(self.batch, batch * 2)
+            if len(hist) >= 2 and hist[-1][1] > 0 and hist[-2][1] > hist[-1][1] and self.tol_ > 0:
+                (i0, s0), (i1, s1) = hist[-2], hist[-1]
+                rate = math.log(s0 / s1) / max(1, i1 - i0)          # log-decay per iteration
+                left = math.log(s1 / float(self.tol_)) / rate if s1 > float(self.tol_) else 0.0
+                batch = int(max(1, min(self.batch, math.floor(left * 0.9))))
+        if int(st.done) == 3:
+            # strict stop: keep the labels of that iteration = E-step on the centres it started
+            # from, which the resumed finalize has made the "previous" set
+            strict_labels = self.assign(which=1, labels=True)[0]
         stop = {1: "tol", 2: "max_iter", 3: "strict"}.get(int(st.done), "?")
         centers = self.centers(which=0, centred=False)
         if strict_labels is not None:
