@@ -153,7 +153,8 @@ typedef struct nnc_kmeans_params {
 typedef struct nnc_kmeans_status {
     int32_t iter;      /* completed Lloyd iterations (scikit-learn's n_iter_ when done) */
     int32_t done;      /* 1: centre shift <= tol, 2: max_iter reached, 3: set by host (strict) */
-    int32_t paused;    /* 1: an empty cluster was found; host must relocate, then resume */
+    int32_t paused;    /* 1: an empty cluster was found; host must relocate, then resume.  2: a windowed
+                          relocation could not be proven (nnc_kmeans_relocate_checked): redo it in full */
     int32_t n_empty;   /* number of empty clusters when paused */
     float shift_tot;   /* last sum of squared centre shifts (float32, NumPy order) */
     float tol;
@@ -212,6 +213,30 @@ int nnc_topm_compact_f32(const float *d, const float *x, int64_t n, uint32_t thr
  * in descending order (nkeys of them, the same on every rank); the i-th empty cluster takes the
  * i-th sample, whose value travels in the key and whose current cluster is re-derived exactly. */
 int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream);
+
+/* The same selection without a pass over the whole vector, for a VALUE-SORTED x (nnc_sort_f32),
+ * single rank.  Inside a cluster the distance falls monotonically towards the centre, so the
+ * farthest samples sit at the ends of each cluster's stretch of the sorted vector; the label
+ * counts of the paused iteration locate those stretches.
+ *   nnc_kmeans_reloc_candidates: gathers the `window` samples either side of every cluster
+ *     boundary (and at both ends of x) into cand_x_dev[cap] (cap >= 2 * window * (k + 1), the
+ *     unused tail is zero-filled), their positions into win_dev (16 * (k + 2) bytes) and
+ *     {n_cand, n_windows, bad, window} into meta_dev[4].
+ *   The caller runs nnc_kmeans_assign on cand_x_dev (n = cap, dist_out) for the exact distances.
+ *   nnc_kmeans_relocate_checked: picks the n_empty largest keys (distance bits << 32 | ordered
+ *     value bits) among the n_cand candidates into keys_out_dev[n_empty] (descending), proves
+ *     that no sample outside the windows can be among the n_empty farthest (every stretch
+ *     between windows lies outside the zones of all centres but one and ends strictly below the
+ *     n_empty-th key's distance) and then relocates as nnc_kmeans_relocate.  If the proof fails
+ *     nothing is changed, the following nnc_kmeans_finalize(resume = 1) leaves the state paused
+ *     with status.paused = 2, and the caller repeats the relocation with the full-pass
+ *     selection above. */
+int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window,
+                                float *cand_x_dev, int64_t cap, void *win_dev, int32_t *meta_dev, void *stream);
+int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, const float *cand_d_dev, const void *win_dev,
+                                const int32_t *meta_dev, int32_t n_empty, int64_t *keys_out_dev, void *stream);
+/* diagnostics: why the last proof failed (0 = it held); synchronous */
+int nnc_debug_reloc_fail(void *ws, int32_t *host_out);
 /* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence
  * test, _kmeans.py:717); nnc_kmeans_set_done_if sets done = done_code when *flag_dev != 0. */
 int nnc_labels_equal(const void *a, const void *b, int64_t n, int label_bytes, int32_t *flag_dev, void *stream);

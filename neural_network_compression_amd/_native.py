@@ -78,6 +78,9 @@ SIGNATURES = {
     "nnc_topm_hist_f32": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, ctypes.c_uint32, c_void_p, c_void_p]),
     "nnc_topm_compact_f32": (c_int, [c_void_p, c_void_p, c_i64, ctypes.c_uint32, c_void_p, c_i64, c_void_p, c_void_p]),
     "nnc_kmeans_relocate": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
+    "nnc_kmeans_reloc_candidates": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
+    "nnc_kmeans_relocate_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),
+    "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),

@@ -646,13 +646,15 @@ struct KmTab {
     int32_t ku;              // number of DISTINCT centre values = entries of cand/orig; equal centres never win (ties go to the lowest index)
     int32_t pad_[2];
     uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 31) << 11)
+    double zl[NNC_KMAX], zr[NNC_KMAX]; // zone of every distinct centre: outside [zl, zr] (centred x) it cannot be the float32 arg-min
 };
 
 struct KmWs {
     nnc_kmeans_status st;
     nnc_kmeans_params p;
     int32_t cur;       // which KmTab / centre set is current
-    int32_t glog2, rlog2, pad0;
+    int32_t glog2, rlog2;
+    int32_t reloc_fail; // the windowed farthest-sample selection could not prove its result: redo it the long way
     float inv;         // cells per unit: cell = (int)((x~ - lo) * inv)
     float pad1[3];
     float c[2][NNC_KMAX];        // centred centres in ORIGINAL index order; [cur] current, [cur^1] previous
@@ -1258,6 +1260,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         return;
     }
     if (mode == FIN_FROM_PARTIALS && ws->st.paused && !resume) return;
+    if (resume && ws->reloc_fail) { // unproven windowed selection: stay paused, tell the host
+        if (tid == 0) ws->st.paused = 2;
+        return;
+    }
     const int k = ws->p.k;
     int cur = ws->cur;
 
@@ -1491,6 +1497,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
                         left = fmax(left, mid - E / delta);
                     }
                 }
+                tab->zl[p] = left; tab->zr[p] = right;
                 gp = G - 1; hp_ = 0;
                 if (inv > 0.0) {
                     const double qa = (right - lo) / ra; // may be +-inf
@@ -1606,7 +1613,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
         ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
-        ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv;
+        ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
         float c = centers_init[j] - p.x_mean; // init -= X_mean (float32)
@@ -1986,11 +1993,12 @@ extern "C" int nnc_topm_compact_f32(const float *d, const float *x, int64_t n, u
 // (low 32 bits, order-preserving float bits); its cluster is re-derived with scikit-learn's exact
 // float32 expression over all centres.  Every rank applies the same edits to its copy.
 // Nothing happens when the largest distance is zero.
-__global__ __launch_bounds__(KM_THREADS) void k_relocate(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys)
+struct KmRelocLds { int empty_id[NNC_KMAX]; int wave_cnt[KM_THREADS / 64]; float cen[NNC_KMAX]; };
+
+__device__ void km_relocate_body(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys, KmRelocLds *lds)
 {
-    __shared__ int empty_id[NNC_KMAX];
-    __shared__ int wave_cnt[KM_THREADS / 64];
-    __shared__ float cen[NNC_KMAX];
+    int *empty_id = lds->empty_id, *wave_cnt = lds->wave_cnt;
+    float *cen = lds->cen;
     const int tid = threadIdx.x;
     const int k = ws->p.k;
     const float *ccur = ws->c[ws->cur];
@@ -2036,6 +2044,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_relocate(KmWs *__restrict__ ws, 
     }
 }
 
+__global__ __launch_bounds__(KM_THREADS) void k_relocate(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys)
+{
+    __shared__ KmRelocLds lds;
+    if (threadIdx.x == 0) ws->reloc_fail = 0;
+    km_relocate_body(ws, keys, nkeys, &lds);
+}
+
 extern "C" int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream)
 {
     if (!ws || !keys_sorted_dev || nkeys < 0) return fail(NNC_EINVAL, "nnc_kmeans_relocate: bad argument");
@@ -2043,6 +2058,329 @@ extern "C" int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int
     hipLaunchKernelGGL(k_relocate, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws),
                        reinterpret_cast<const long long *>(keys_sorted_dev), nkeys);
     LAUNCHCHK("k_relocate");
+    return NNC_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// Windowed selection on a VALUE-SORTED vector.  Inside one cluster the squared distance to the
+// centre falls monotonically towards the centre, so the farthest samples sit at the two ends of
+// every cluster's stretch of the sorted vector.  The label counts of the paused iteration give
+// those stretches (prefix sums over the centres in value order), so the candidates are the
+// `window` samples either side of every boundary (and at the two ends of the vector):
+// 2 * window * (k + 1) values instead of millions.  Candidates get their exact label / distance
+// from the ordinary E-step kernel; k_reloc_verify then proves that no sample outside the windows
+// can enter the top n_empty: every stretch between two windows must lie in single-candidate
+// cells of one centre (so its distances are monotone either side of that centre) and the
+// distances at both of its ends must be strictly below the n_empty-th best candidate's.
+// Otherwise the workspace is flagged (reloc_fail), the checked relocation and the resumed
+// finalize do nothing, the status reports paused = 2 and the host falls back to the full pass.
+// --------------------------------------------------------------------------------------
+struct KmWin { long long start; int len; int off; };
+
+// inclusive scan (sum or running maximum) over up to 2 * KM_THREADS values, two consecutive ones per thread
+template <bool MAXOP>
+__device__ __forceinline__ void block_scan2(long long &a0, long long &a1, long long *wave_tot)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto op = [](long long x, long long y) -> long long { return MAXOP ? (x > y ? x : y) : x + y; };
+    a1 = op(a0, a1);
+    long long s = a1;
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long t = __shfl_up(s, off);
+        if (lane >= off) s = op(s, t);
+    }
+    if (lane == 63) wave_tot[wv] = s;
+    __syncthreads();
+    long long pre = 0; // both uses scan non-negative values
+    for (int w = 0; w < wv; w++) pre = op(pre, wave_tot[w]);
+    __syncthreads();
+    const long long prev = __shfl_up(s, 1);
+    const long long before = (lane == 0) ? pre : op(pre, prev); // everything before this thread's pair
+    a0 = op(before, a0);
+    a1 = op(before, a1);
+}
+
+#define KM_RELOC_WMAX 8192 // a window side never grows beyond this many samples
+#define KM_SURV_MAX 2048   // survivors of the histogram cut that are ranked exactly
+
+// one workgroup: the window table.  meta = {n_cand, n_windows, bad, window}
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, const KmWs *__restrict__ ws,
+                                                              int W, long long cap, KmWin *__restrict__ win, int *__restrict__ meta)
+{
+    __shared__ long long bnd[2 * KM_THREADS + 2];
+    __shared__ long long wst[2 * KM_THREADS], wen[2 * KM_THREADS];
+    __shared__ long long wave_tot[KM_THREADS / 64];
+    const int tid = threadIdx.x;
+    const KmTab *tab = &ws->tab[ws->cur];
+    const int kt = tab->ku, k = ws->p.k;
+    const float mean = ws->p.x_mean;
+    const int i0 = 2 * tid, i1 = 2 * tid + 1;
+    long long a0 = (i0 < kt) ? ws->partials_local[k + tab->orig[i0]] : 0;
+    long long a1 = (i1 < kt) ? ws->partials_local[k + tab->orig[i1]] : 0;
+    block_scan2<false>(a0, a1, wave_tot);
+    if (tid == 0) bnd[0] = 0;
+    bnd[i0 + 1] = a0; bnd[i1 + 1] = a1;   // bnd[j] = samples in the first j clusters (value order), j = 0 .. kt
+    __syncthreads();
+    const int nwin = kt + 1;
+    const int bad = (bnd[kt] != n) ? 1 : 0; // the counts must be those of this very vector
+    // Window j surrounds position bnd[j].  Each side starts at W samples and doubles until its
+    // outermost sample has left the zone in which the float32 arg-min between the two
+    // neighbouring centres is open (wide when two centres are close): the proof needs that.
+    for (int j = tid; j < 2 * KM_THREADS; j += KM_THREADS) {
+        long long st = 0, en = 0;
+        if (j < nwin) {
+            const long long b = bnd[j];
+            long long wl = W, wr = W;
+            if (j > 0 && j < kt && n > 0) {
+                const double zr = tab->zr[j - 1], zl = tab->zl[j];
+                bool more_r = true, more_l = true;
+                while (more_r || more_l) { // both probes of a round are in flight together
+                    const long long pr = b + wr - 1, pl = b - wl;
+                    const float vr = (more_r && pr < n - 1) ? xs[pr] : 0.0f;
+                    const float vl = (more_l && pl > 0) ? xs[pl] : 0.0f;
+                    if (more_r) { if (pr >= n - 1 || (double)(vr - mean) > zr || wr >= KM_RELOC_WMAX) more_r = false; else wr *= 2; }
+                    if (more_l) { if (pl <= 0 || (double)(vl - mean) < zl || wl >= KM_RELOC_WMAX) more_l = false; else wl *= 2; }
+                }
+            }
+            st = b - wl < 0 ? 0 : b - wl;
+            en = b + wr > n ? n : b + wr;
+        }
+        wst[j] = st; wen[j] = en;
+    }
+    __syncthreads();
+    long long e0 = wen[i0], e1 = wen[i1];
+    block_scan2<true>(e0, e1, wave_tot); // running maximum of the window ends
+    if (tid == 0) bnd[0] = 0;
+    bnd[i0 + 1] = e0; bnd[i1 + 1] = e1;  // bnd[j + 1] = end of windows 0 .. j   (all reads of bnd[] as boundaries are behind a barrier)
+    __syncthreads();
+    long long l0 = 0, l1 = 0, s0 = 0, s1 = 0;
+    if (i0 < nwin) { s0 = wst[i0] > bnd[i0] ? wst[i0] : bnd[i0]; l0 = bnd[i0 + 1] - s0; if (l0 <= 0) { l0 = 0; s0 = bnd[i0 + 1]; } }
+    if (i1 < nwin) { s1 = wst[i1] > bnd[i1] ? wst[i1] : bnd[i1]; l1 = bnd[i1 + 1] - s1; if (l1 <= 0) { l1 = 0; s1 = bnd[i1 + 1]; } }
+    const long long len0 = l0, len1 = l1;
+    block_scan2<false>(l0, l1, wave_tot);
+    if (i0 < nwin) { KmWin w; w.start = s0; w.len = (int)len0; w.off = l0 <= cap ? (int)(l0 - len0) : 0; win[i0] = w; }
+    if (i1 < nwin) { KmWin w; w.start = s1; w.len = (int)len1; w.off = l1 <= cap ? (int)(l1 - len1) : 0; win[i1] = w; }
+    if (tid == (nwin - 1) / 2) {
+        const long long total = ((nwin - 1) & 1) ? l1 : l0;
+        const int over = total > cap ? 1 : 0;
+        meta[0] = over ? 0 : (int)total; meta[1] = nwin; meta[2] = bad | over; meta[3] = W;
+    }
+}
+
+// the candidates themselves (any grid): one wave per window, the unused tail of cand_x is zeroed
+__global__ __launch_bounds__(256) void k_reloc_fill(const float *__restrict__ xs, const KmWin *__restrict__ win,
+                                                    const int *__restrict__ meta, float *__restrict__ cand_x, long long cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const int nwin = meta[1], total = meta[0];
+    if (!meta[2])
+        for (int j = wave; j < nwin; j += nwaves) {
+            const KmWin w = win[j];
+            for (int i = lane; i < w.len; i += 64) cand_x[w.off + i] = xs[w.start + i];
+        }
+    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long long i = total + tid; i < cap; i += (long long)gridDim.x * blockDim.x) cand_x[i] = 0.0f;
+}
+
+// One workgroup: the n_empty largest keys among the candidates (histogram cut on the distance
+// bits, refined while crowded, exact ranking of the survivors), the proof that nothing outside
+// the windows can beat them, and -- if it holds -- the relocation itself.
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
+                                                             const float *__restrict__ cand_d, const KmWin *__restrict__ win,
+                                                             const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out)
+{
+    __shared__ __align__(8) unsigned hist[4096];
+    __shared__ unsigned long long surv[KM_SURV_MAX];
+    __shared__ int wave_i[KM_THREADS / 64];
+    __shared__ int s_cut, s_above, s_ge, s_nsurv, s_bad;
+    __shared__ KmRelocLds rl;
+    __shared__ double zl_s[NNC_KMAX];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_cand = meta[0];
+    {
+        int bad0 = meta[2] ? 1 : 0;
+        if (n_empty < 1 || n_cand < n_empty) bad0 |= 2;
+        if (bad0) { if (tid == 0) ws->reloc_fail = bad0; return; }
+    }
+    // Coalesced 16-byte reads; neighbours in position have similar distances, so most of the time a
+    // whole wave lands in one bin: one LDS atomic per wave instead of 256 (LDS atomics retire about
+    // one lane per clock).
+    const int nvec = n_cand >> 2; // cand_d is the start of an allocation: 16-byte aligned
+    const uint4 *d4 = reinterpret_cast<const uint4 *>(cand_d);
+    unsigned prefix = 0, thr = 0;
+    int pshift = -1, above = 0, total_ge = n_cand;
+    const int shifts[3] = {19, 7, 0}, widths[3] = {12, 12, 7};
+    for (int lvl = 0; lvl < 3; lvl++) {
+        const int shift = shifts[lvl], width = widths[lvl];
+        const unsigned mask = (1u << width) - 1u;
+        for (int i = tid; i < 4096; i += KM_THREADS) hist[i] = 0;
+        if (tid == 0) { s_cut = 0; s_above = above; s_ge = total_ge; }
+        __syncthreads();
+        const unsigned NOBIN = 0xFFFFu;
+        auto bin_of = [&](unsigned u) -> unsigned { return (pshift < 0 || (u >> pshift) == prefix) ? ((u >> shift) & mask) : NOBIN; };
+        for (int v0 = 0; v0 < nvec; v0 += KM_THREADS) { // wave-uniform trip count
+            const int v = v0 + tid;
+            const bool have = v < nvec;
+            const uint4 q = have ? d4[v] : make_uint4(0u, 0u, 0u, 0u);
+            const unsigned b0 = have ? bin_of(q.x) : NOBIN, b1 = have ? bin_of(q.y) : NOBIN;
+            const unsigned b2 = have ? bin_of(q.z) : NOBIN, b3 = have ? bin_of(q.w) : NOBIN;
+            const unsigned long long act = __ballot(have);
+            if (!act) continue;
+            const unsigned first = (unsigned)__shfl((int)b0, __ffsll((long long)act) - 1);
+            const bool same = !have || (b0 == first && b1 == first && b2 == first && b3 == first);
+            if (__all(same)) {
+                if (first != NOBIN && lane == 0) atomicAdd(&hist[first], 4u * (unsigned)__popcll(act));
+            } else if (have) {
+                unsigned rb = b0, rc = 1;
+                if (b1 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b1; rc = 1; }
+                if (b2 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b2; rc = 1; }
+                if (b3 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b3; rc = 1; }
+                if (rb != NOBIN) atomicAdd(&hist[rb], rc);
+            }
+        }
+        for (int i = (nvec << 2) + tid; i < n_cand; i += KM_THREADS) {
+            const unsigned bn = bin_of(__float_as_uint(cand_d[i]));
+            if (bn != NOBIN) atomicAdd(&hist[bn], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins 4t .. 4t+3; count of everything in higher bins via a block prefix sum
+        const unsigned h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        int own = (int)(h0 + h1 + h2 + h3), sc = own;
+        for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(sc, off); if (lane >= off) sc += t; }
+        if (lane == 63) wave_i[wv] = sc;
+        __syncthreads();
+        int pre = 0, tot = 0;
+        for (int w = 0; w < KM_THREADS / 64; w++) { const int v = wave_i[w]; if (w < wv) pre += v; tot += v; }
+        int run = above + (tot - (pre + sc)); // samples above this thread's bins (and above the prefix)
+        const unsigned hb[4] = {h0, h1, h2, h3};
+        for (int q = 3; q >= 0; q--) {
+            const int before = run;
+            run += (int)hb[q];
+            if (before < n_empty && run >= n_empty) { s_cut = 4 * tid + q; s_above = before; s_ge = run; } // exactly one thread, one bin
+        }
+        __syncthreads();
+        const int bcut = s_cut;
+        prefix = (pshift < 0) ? (unsigned)bcut : ((prefix << width) | (unsigned)bcut);
+        pshift = shift;
+        above = s_above;
+        total_ge = s_ge;
+        thr = prefix << shift;
+        __syncthreads();
+        if (total_ge <= KM_SURV_MAX) break;
+    }
+    int bad = 0;
+    if (total_ge > KM_SURV_MAX) bad |= 128; // a crowd of exactly equal distances at the cut
+    if (tid == 0) { s_nsurv = 0; s_bad = 0; }
+    for (int i = tid; i < KM_SURV_MAX; i += KM_THREADS) surv[i] = 0ull; // padding sorts last
+    __syncthreads();
+    if (!bad) {
+        auto take = [&](unsigned u, int i) {
+            if (u >= thr) {
+                const int slot = atomicAdd(&s_nsurv, 1);
+                if (slot < KM_SURV_MAX) surv[slot] = ((unsigned long long)u << 32) | (unsigned long long)f32_ordered_bits(cand_x[i]);
+            }
+        };
+        for (int v = tid; v < nvec; v += KM_THREADS) {
+            const uint4 q = d4[v];
+            take(q.x, 4 * v); take(q.y, 4 * v + 1); take(q.z, 4 * v + 2); take(q.w, 4 * v + 3);
+        }
+        for (int i = (nvec << 2) + tid; i < n_cand; i += KM_THREADS) take(__float_as_uint(cand_d[i]), i);
+    }
+    __syncthreads();
+    const int m = min(s_nsurv, KM_SURV_MAX);
+    if (!bad && m < n_empty) bad |= 2;
+    if (!bad) {
+        // bitonic sort, descending, of the survivors (padded with zeros to a power of two)
+        int M = 2;
+        while (M < m) M <<= 1;
+        for (int size = 2; size <= M; size <<= 1)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                __syncthreads();
+                for (int t = tid; t < (M >> 1); t += KM_THREADS) {
+                    const int lo_i = 2 * t - (t & (stride - 1)), hi_i = lo_i + stride;
+                    const bool up = (lo_i & size) == 0;
+                    const unsigned long long ka = surv[lo_i], kb = surv[hi_i];
+                    if ((ka < kb) == up) { surv[lo_i] = kb; surv[hi_i] = ka; }
+                }
+            }
+        __syncthreads();
+        for (int r = tid; r < n_empty; r += KM_THREADS) keys_out[r] = (long long)surv[r];
+    }
+    __syncthreads();
+    if (!bad) {
+        const unsigned dT = (unsigned)(surv[n_empty - 1] >> 32);
+        const KmTab *tab = &ws->tab[ws->cur];
+        const float mean = ws->p.x_mean;
+        const int ku = tab->ku, nwin = meta[1];
+        // zone ends into LDS (the right ends over the histogram, which is free now)
+        double *zr_s = reinterpret_cast<double *>(hist); // 4096 * 4 B = 2048 doubles
+        for (int q = tid; q < ku; q += KM_THREADS) { zr_s[q] = tab->zr[q]; zl_s[q] = tab->zl[q]; }
+        __syncthreads();
+        for (int j = tid; j + 1 < nwin; j += KM_THREADS) {
+            const KmWin a = win[j], b = win[j + 1];
+            if (b.start > a.start + a.len) { // samples between the two windows that are no candidates
+                // the candidates either side of the stretch (candidates are stored in position order, so an
+                // empty window -- an empty cluster's boundary coincides with its neighbour's -- is skipped over)
+                const int iu = a.off + a.len - 1, iw = b.off;
+                if (iu < 0 || iw >= n_cand) { bad |= 4; continue; }
+                const float u = cand_x[iu], w = cand_x[iw];
+                const unsigned du = __float_as_uint(cand_d[iu]), dw = __float_as_uint(cand_d[iw]);
+                // every value in [u, w] must have centre j (value order) as its only candidate:
+                // above the zones of all smaller centres, below the zones of all larger ones
+                const double uc = (double)(u - mean), wc = (double)(w - mean);
+                for (int q = 0; q < j && q < ku; q++) if (!(uc > zr_s[q])) bad |= 8;
+                for (int q = j + 1; q < ku; q++) if (!(wc < zl_s[q])) bad |= 16;
+                if (!(du < dT)) bad |= 32;
+                if (!(dw < dT)) bad |= 64;
+            }
+        }
+    }
+    // reason bits (diagnostics): 1 counts/capacity, 2 too few candidates, 4 window table, 8 / 16 lower / upper end of a
+    // stretch inside another centre's zone, 32 / 64 lower / upper end not strictly below the cut, 128 tie crowd
+    if (bad) atomicOr(&s_bad, bad);
+    __syncthreads();
+    const int any_bad = s_bad;
+    if (tid == 0) ws->reloc_fail = any_bad;
+    if (any_bad) return;
+    __threadfence_block();
+    km_relocate_body(ws, keys_out, n_empty, &rl);
+}
+
+extern "C" int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window,
+                                           float *cand_x_dev, int64_t cap, void *win_dev, int32_t *meta_dev, void *stream)
+{
+    int rc = km_check(ws, p, "nnc_kmeans_reloc_candidates");
+    if (rc) return rc;
+    if (!x_sorted || !cand_x_dev || !win_dev || !meta_dev || window < 1) return fail(NNC_EINVAL, "nnc_kmeans_reloc_candidates: bad argument");
+    if (cap < 2 * (int64_t)window * (p->k + 1) || cap > 0x7FFFFFFF) return fail(NNC_ENOSPACE, "nnc_kmeans_reloc_candidates: cap must be in [2 * window * (k + 1), 2^31)");
+    hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
+                       reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
+                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev));
+    LAUNCHCHK("k_reloc_windows");
+    const int grid = (int)std::min<int64_t>(256, (cap + 16383) / 16384 + p->k / 4 + 1);
+    hipLaunchKernelGGL(k_reloc_fill, dim3(grid), dim3(256), 0, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
+                       reinterpret_cast<const int *>(meta_dev), cand_x_dev, (long long)cap);
+    LAUNCHCHK("k_reloc_fill");
+    return NNC_OK;
+}
+
+extern "C" int nnc_debug_reloc_fail(void *ws, int32_t *host_out)
+{
+    if (!ws || !host_out) return fail(NNC_EINVAL, "nnc_debug_reloc_fail: null pointer");
+    HIPCHK(hipMemcpy(host_out, &reinterpret_cast<KmWs *>(ws)->reloc_fail, sizeof(int32_t), hipMemcpyDeviceToHost));
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, const float *cand_d_dev, const void *win_dev,
+                                           const int32_t *meta_dev, int32_t n_empty, int64_t *keys_out_dev, void *stream)
+{
+    if (!ws || !cand_x_dev || !cand_d_dev || !win_dev || !meta_dev || !keys_out_dev || n_empty < 1 || n_empty > NNC_KMAX)
+        return fail(NNC_EINVAL, "nnc_kmeans_relocate_checked: bad argument");
+    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x_dev, cand_d_dev,
+                       reinterpret_cast<const KmWin *>(win_dev), reinterpret_cast<const int *>(meta_dev), (int)n_empty,
+                       reinterpret_cast<long long *>(keys_out_dev));
+    LAUNCHCHK("k_reloc_select");
     return NNC_OK;
 }
 

@@ -71,7 +71,8 @@ class DeviceKMeans:
     """One fit = one instance.  ``x`` float32, 1-D, contiguous, CUDA."""
 
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
-                 batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None):
+                 batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
+                 reloc: str = "auto"):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -124,6 +125,11 @@ class DeviceKMeans:
         off = pptr - self.ws.data_ptr()
         self.partials = self.ws[off: off + 16 * self.k].view(torch.int64)
         self.n_relocations = 0
+        self.n_reloc_windowed = 0   # relocation events settled by the windowed selection
+        self.n_reloc_full = 0       # ... by the full distance pass
+        if reloc not in ("auto", "full"):
+            raise ValueError("reloc must be 'auto' or 'full'")
+        self.reloc = reloc
         # pinned host landing zones for the small device->host reads (status block, 4096-bin histogram)
         self._status_pin = torch.empty(ctypes.sizeof(nat.KMeansStatus), dtype=torch.uint8, pin_memory=True)
         self._status_host = nat.KMeansStatus.from_address(self._status_pin.data_ptr())
@@ -132,7 +138,8 @@ class DeviceKMeans:
         # labels, values and relocation distances always come from the original vector.
         if sort is None:
             sort = n >= SORT_MIN_WEIGHTS
-        self.x_iter = self._sorted_copy(x) if (sort and n > 0) else x
+        self.sorted = bool(sort and n > 0)
+        self.x_iter = self._sorted_copy(x) if self.sorted else x
         # params.flags bit 0 selects the DIRECT kernel form (runs flushed per wave straight to global atomics,
         # no LDS accumulators, no closing barrier).  Measured slower end to end: it needs > 64 VGPRs (one
         # workgroup per CU) and, on pruned tensors, thousands of waves end on the zero cluster's address.
@@ -228,6 +235,38 @@ class DeviceKMeans:
         key = (d.view(torch.int32).to(torch.int64) << 32) | ordered
         return torch.topk(key, m, largest=True, sorted=True).values
 
+    RELOC_WINDOW_MIN = 64
+    RELOC_WINDOW_MAX = 1024
+
+    def _relocate_windowed(self, n_empty: int) -> bool:
+        """The same relocation from 2 * window * (k + 1) candidates around the cluster boundaries of
+        the value-sorted vector (include/nnc.h, nnc_kmeans_reloc_candidates): no pass over the
+        vector, no host read.  The device proves the selection; if it cannot, the resumed finalize
+        leaves status.paused = 2 and the caller comes back through the full pass."""
+        window = self.RELOC_WINDOW_MIN
+        while window < n_empty:
+            window *= 2
+        if window > self.RELOC_WINDOW_MAX or 2 * window > self.n:
+            return False
+        cap = 8 * window * (self.k + 1)   # window sides double where two centres are close (wide open zone)
+        cand = torch.empty(cap, dtype=torch.float32, device=self.dev)
+        dist = torch.empty(cap, dtype=torch.float32, device=self.dev)
+        win = torch.empty(16 * (self.k + 2), dtype=torch.uint8, device=self.dev)
+        meta = torch.empty(4, dtype=torch.int32, device=self.dev)
+        keys = torch.empty(n_empty, dtype=torch.int64, device=self.dev)
+        ws = self.ws.data_ptr()
+        nat.check(self.L.nnc_kmeans_reloc_candidates(self.x_iter.data_ptr(), ws, ctypes.byref(self.p), window, cand.data_ptr(), cap,
+                                                     win.data_ptr(), meta.data_ptr(), self.stream))
+        pc = nat.KMeansParams.from_buffer_copy(self.p)
+        pc.n = cap
+        pc.n_total = max(cap, int(self.p.n_total))
+        nat.check(self.L.nnc_kmeans_assign(cand.data_ptr(), ws, ctypes.byref(pc), 0, None, 1, None, dist.data_ptr(), None, self.stream))
+        nat.check(self.L.nnc_kmeans_relocate_checked(ws, cand.data_ptr(), dist.data_ptr(), win.data_ptr(), meta.data_ptr(),
+                                                     n_empty, keys.data_ptr(), self.stream))
+        nat.check(self.L.nnc_kmeans_finalize(ws, 1, self.stream))
+        self._reloc_meta = meta   # {n_cand, n_windows, bad, window}: diagnostics (tools/debug_reloc.py)
+        return True
+
     def _relocate_and_resume(self, st) -> None:
         """scikit-learn's _relocate_empty_clusters_dense (_k_means_common.pyx:167-211) for a
         paused iteration, then resume the finalize step; everything runs on the device (one small
@@ -240,6 +279,16 @@ class DeviceKMeans:
         samples (up to ties at the cut), the same pairing whenever n_empty == 1, an implementation-
         defined (CPU-dispatch dependent) pairing otherwise."""
         n_empty = int(st.n_empty)
+        strict_check = st.iter >= 1 and st.same_counts
+        if (self.reloc == "auto" and self.sorted and self.group is None and int(st.paused) == 1 and not strict_check
+                and self._relocate_windowed(n_empty)):
+            self.n_relocations += 1
+            self.n_reloc_windowed += 1   # provisional: a failed proof comes back as paused == 2 and is redone in full
+            return
+        if int(st.paused) == 2:
+            self.n_relocations -= 1
+            self.n_reloc_windowed -= 1
+        self.n_reloc_full += 1
         xs = self.x_iter  # any order will do; the value-sorted copy makes the histogram cheap
         hist0 = torch.empty(4096, dtype=torch.int64, device=self.dev)
         _, _, d = self._assign_on(xs, which=0, labels=False, distances=True, dist_hist=hist0)

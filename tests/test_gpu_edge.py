@@ -103,3 +103,68 @@ def test_prune_edge_cases(km_mod):
     wo = w.copy()
     assert np.array_equal(utility.prune_weigth(w, 0, True), orc.prune_weigth(wo, 0, True))  # q = 0: nothing pruned
     assert not utility.prune_weigth(w, 0, True).any()
+
+
+def _fit_pair(kmeans, x, init):
+    """windowed ('auto') and full-pass relocation against the oracle; returns the 'auto' fit object"""
+    ob = orc.kmeans_lloyd(x, init, accum="B")
+    kms = {}
+    for mode in ("auto", "full"):
+        km = kmeans.DeviceKMeans(torch.from_numpy(np.ascontiguousarray(x)).cuda(), init, reloc=mode)
+        model, _ = km.fit()
+        assert model.n_iter_ == ob.n_iter_, (mode, model.n_iter_, ob.n_iter_)
+        assert np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), mode
+        assert np.array_equal(model.labels_, ob.labels_), mode
+        kms[mode] = km
+    assert kms["full"].n_reloc_windowed == 0
+    assert kms["auto"].n_relocations == kms["full"].n_relocations
+    return kms["auto"]
+
+
+def test_windowed_relocation_on_sorted_vectors(km_mod):
+    """Empty clusters on vectors long enough to be iterated value-sorted: the candidates come from
+    windows around the cluster boundaries, the device proves the choice or the full pass repeats it."""
+    kmeans, _ = km_mod
+    # centres in the pruned gap and beyond the tails
+    x = synth.weights((300_000,), 31)
+    x[np.abs(x) < 0.05] = 0
+    km = _fit_pair(kmeans, x, np.linspace(x.min() * 1.5, x.max() * 1.5, 64).astype(np.float32))
+    assert km.n_relocations >= 1 and km.n_reloc_windowed >= 1
+    # duplicate initial centres (what the density init produces), many empties at once
+    x = synth.weights((200_000,), 32)
+    qs = np.quantile(x.astype(np.float64), np.linspace(0.01, 0.99, 40)).astype(np.float32)
+    init = np.repeat(qs, 5)[:190]
+    km = _fit_pair(kmeans, x, init)
+    assert km.n_relocations >= 1 and km.n_reloc_windowed >= 1
+    # few distinct values, long runs of equal samples around every boundary
+    x = (np.round(synth.weights((150_000,), 33) * 200) / 200).astype(np.float32)
+    init = np.repeat(np.linspace(x.min(), x.max(), 12).astype(np.float32), 2)
+    km = _fit_pair(kmeans, x, init)
+    assert km.n_relocations >= 1
+    # a cluster narrower than the window, more empties than the smallest window
+    x = np.concatenate([synth.weights((100_000,), 34), np.linspace(0.4, 0.5, 40).astype(np.float32)])
+    init = np.concatenate([np.full(100, 0.45, dtype=np.float32), np.linspace(-0.2, 0.2, 28).astype(np.float32)])
+    km = _fit_pair(kmeans, x, init)
+    assert km.n_relocations >= 1
+
+
+def test_windowed_relocation_full_size_equals_full_pass(km_mod):
+    """BASELINE configs[3] workload (25 M weights pruned at 1 sigma, density init, K = 257): thirteen
+    relocation events; the windowed selection and the full distance pass give the same fit, bit for bit."""
+    kmeans, ops = km_mod
+    from neural_network_compression_amd import pipeline
+    x = torch.from_numpy(synth.weights((25_000_000,), 4000)).cuda()
+    ops.prune_(x, 1.0, True)
+    cdfs = pipeline.weight_distribution(x, True)
+    space = pipeline.initial_centroids(x, 8, "density", cdfs)
+    fits = {}
+    for mode in ("auto", "full"):
+        km = kmeans.DeviceKMeans(x, space, reloc=mode)
+        model, vals = km.fit()
+        fits[mode] = (km, model, vals)
+    (ka, ma, va), (kf, mf, vf) = fits["auto"], fits["full"]
+    assert ka.n_reloc_windowed >= 5 and kf.n_reloc_windowed == 0 and ka.n_relocations == kf.n_relocations
+    assert ma.n_iter_ == mf.n_iter_ and ma.stop_reason_ == mf.stop_reason_
+    assert np.array_equal(ma.cluster_centers_, mf.cluster_centers_)
+    assert torch.equal(ma.labels_compact_, mf.labels_compact_)
+    assert torch.equal(va, vf)

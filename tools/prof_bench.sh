@@ -10,7 +10,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print(f"total kernel time {tot/1e6:.2f} ms over {sum(int(r['Calls']) for r in rows)} launches")
-for r in rows[:22]:
+for r in rows[:40]:
     print(f"  {r['Name'][:70]:70s} calls={r['Calls']:>6s} total_ms={float(r['TotalDurationNs'])/1e6:8.3f} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
 PY
 tail -2 $out/bench.log | cut -c1-400
