@@ -108,6 +108,11 @@ size_t nnc_minmax_workspace_bytes(int64_t n);
 int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev, void *ws,
                    size_t ws_bytes, void *stream);
 
+/* min / max over all elements plus signs_dev[0] = #{x < 0}, signs_dev[1] = #{x == 0}: what
+ * nnc_sort_pruned_f32 needs, from the pass the k-means set-up makes anyway. */
+int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
+                         void *stream);
+
 /* counts_dev[b] += #{ i : steps[b] <= x[i] < steps[b+1] }, b = 0..30 (caller zeroes counts_dev). */
 int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps32_dev, int64_t *counts_dev,
                    void *stream);
@@ -134,6 +139,12 @@ int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps
  * (rocPRIM); not part of the per-iteration path.  nnc_kmeans_assign must get the original. */
 size_t nnc_sort_workspace_bytes(int64_t n);
 int nnc_sort_f32(const float *x, int64_t n, float *sorted_out, void *ws, size_t ws_bytes, void *stream);
+/* The same for a pruned vector with n_neg negative and n_zero zero elements (host counts, e.g.
+ * from nnc_minmax_signs_f32): the zeros are not sorted, only partitioned out and filled back
+ * (-0.0 comes back as +0.0).  Any other count gives an unspecified order (never a fault). */
+size_t nnc_sort_pruned_workspace_bytes(int64_t n, int64_t n_neg, int64_t n_zero);
+int nnc_sort_pruned_f32(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float *sorted_out, void *ws,
+                        size_t ws_bytes, void *stream);
 
 typedef struct nnc_kmeans_params {
     int64_t n;         /* length of this rank's shard */
@@ -219,8 +230,8 @@ int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys,
  * farthest samples sit at the ends of each cluster's stretch of the sorted vector; the label
  * counts of the paused iteration locate those stretches.
  *   nnc_kmeans_reloc_candidates: gathers the `window` samples either side of every cluster
- *     boundary (and at both ends of x) into cand_x_dev[cap] (cap >= 2 * window * (k + 1), the
- *     unused tail is zero-filled), their positions into win_dev (16 * (k + 2) bytes) and
+ *     boundary (and at both ends of x) into cand_x_dev[cap] (cap >= 2 * window * (k + 1); the
+ *     tail beyond n_cand is left as it was), their positions into win_dev (16 * (k + 2) bytes) and
  *     {n_cand, n_windows, bad, window} into meta_dev[4].
  *   The caller runs nnc_kmeans_assign on cand_x_dev (n = cap, dist_out) for the exact distances.
  *   nnc_kmeans_relocate_checked: picks the n_empty largest keys (distance bits << 32 | ordered
@@ -235,6 +246,15 @@ int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, const nnc_kmean
                                 float *cand_x_dev, int64_t cap, void *win_dev, int32_t *meta_dev, void *stream);
 int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, const float *cand_d_dev, const void *win_dev,
                                 const int32_t *meta_dev, int32_t n_empty, int64_t *keys_out_dev, void *stream);
+/* All of the above in one call (windows, candidates, distances, selection + proof + relocation,
+ * resumed finalize), no host read.  nnc_kmeans_reloc_window: the window size used for n_empty
+ * empty clusters on a vector of n samples, 0 if the windowed form does not apply (then use the
+ * full pass); scratch: nnc_kmeans_reloc_scratch_bytes(k, window) bytes of device memory, 256-byte
+ * aligned.  Afterwards status.paused is 0 (done) or 2 (not proven: repeat with the full pass). */
+int32_t nnc_kmeans_reloc_window(int64_t n, int32_t n_empty);
+size_t nnc_kmeans_reloc_scratch_bytes(int32_t k, int32_t window);
+int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
+                                 void *scratch_dev, size_t scratch_bytes, void *stream);
 /* diagnostics: why the last proof failed (0 = it held); synchronous */
 int nnc_debug_reloc_fail(void *ws, int32_t *host_out);
 /* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence

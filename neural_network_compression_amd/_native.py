@@ -61,9 +61,12 @@ SIGNATURES = {
     "nnc_apply_mask_f32": (c_int, [c_void_p, c_void_p, c_i64, c_void_p]),
     "nnc_minmax_workspace_bytes": (c_size, [c_i64]),
     "nnc_minmax_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_minmax_signs_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_hist31_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "nnc_sort_workspace_bytes": (c_size, [c_i64]),
     "nnc_sort_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_sort_pruned_workspace_bytes": (c_size, [c_i64, c_i64, c_i64]),
+    "nnc_sort_pruned_f32": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_fix_shift": (c_i32, [c_f32, c_i64]),
     "nnc_kmeans_workspace_bytes": (c_size, [c_i32]),
     "nnc_kmeans_init": (c_int, [c_void_p, c_size, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
@@ -80,6 +83,9 @@ SIGNATURES = {
     "nnc_kmeans_relocate": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_kmeans_reloc_candidates": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p]),
     "nnc_kmeans_relocate_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p]),
+    "nnc_kmeans_reloc_window": (c_i32, [c_i64, c_i32]),
+    "nnc_kmeans_reloc_scratch_bytes": (c_size, [c_i32, c_i32]),
+    "nnc_kmeans_relocate_windowed": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p]),
     "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),

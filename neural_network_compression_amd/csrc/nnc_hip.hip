@@ -429,7 +429,7 @@ extern "C" int nnc_apply_mask_f32(float *x, const uint8_t *mask, int64_t n, void
 // ======================================================================================
 // 3. min / max / count, 31-bin histogram, bincount
 // ======================================================================================
-struct MinMaxPartial { float mn, mx; unsigned long long cnt; };
+struct MinMaxPartial { float mn, mx; unsigned long long cnt; unsigned long long neg, zer; };
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int64_t n, int skip_zeros,
@@ -437,10 +437,11 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int
 {
     float mn = INFINITY, mx = -INFINITY;
     unsigned long long cnt = 0;
+    unsigned neg = 0, zer = 0; // per thread: well below 2^32
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
-#define MM1(v) do { float v_ = (v); bool use_ = !(skip_zeros && v_ == 0.0f); if (use_) { mn = fminf(mn, v_); mx = fmaxf(mx, v_); cnt++; } } while (0)
+#define MM1(v) do { float v_ = (v); neg += (v_ < 0.0f); zer += (v_ == 0.0f); bool use_ = !(skip_zeros && v_ == 0.0f); if (use_) { mn = fminf(mn, v_); mx = fmaxf(mx, v_); cnt++; } } while (0)
     if (VEC) {
         const int64_t nvec = n >> 2;
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -452,42 +453,49 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int
     }
     for (int64_t i = done + tid; i < n; i += nthreads) MM1(x[i]);
 #undef MM1
+    unsigned long long negl = neg, zerl = zer;
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_down(mn, off));
         mx = fmaxf(mx, __shfl_down(mx, off));
         cnt += __shfl_down(cnt, off);
+        negl += __shfl_down(negl, off);
+        zerl += __shfl_down(zerl, off);
     }
     __shared__ MinMaxPartial sh[4];
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6].mn = mn; sh[threadIdx.x >> 6].mx = mx; sh[threadIdx.x >> 6].cnt = cnt; }
+    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = negl; q.zer = zerl; sh[threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
         MinMaxPartial p = sh[0];
-        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; }
+        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer; }
         part[blockIdx.x] = p;
     }
 }
 
 __global__ __launch_bounds__(256) void k_minmax_final(const MinMaxPartial *__restrict__ part, int nparts,
-                                                      float *__restrict__ out, long long *__restrict__ count)
+                                                      float *__restrict__ out, long long *__restrict__ count,
+                                                      long long *__restrict__ signs)
 {
     float mn = INFINITY, mx = -INFINITY;
-    unsigned long long cnt = 0;
+    unsigned long long cnt = 0, neg = 0, zer = 0;
     for (int i = threadIdx.x; i < nparts; i += 256) {
-        mn = fminf(mn, part[i].mn); mx = fmaxf(mx, part[i].mx); cnt += part[i].cnt;
+        mn = fminf(mn, part[i].mn); mx = fmaxf(mx, part[i].mx); cnt += part[i].cnt; neg += part[i].neg; zer += part[i].zer;
     }
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_down(mn, off));
         mx = fmaxf(mx, __shfl_down(mx, off));
         cnt += __shfl_down(cnt, off);
+        neg += __shfl_down(neg, off);
+        zer += __shfl_down(zer, off);
     }
     __shared__ MinMaxPartial sh[4];
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6].mn = mn; sh[threadIdx.x >> 6].mx = mx; sh[threadIdx.x >> 6].cnt = cnt; }
+    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = neg; q.zer = zer; sh[threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
         MinMaxPartial p = sh[0];
-        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; }
+        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer; }
         out[0] = p.mn; out[1] = p.mx;
         if (count) *count = (long long)p.cnt;
+        if (signs) { signs[0] = (long long)p.neg; signs[1] = (long long)p.zer; }
     }
 }
 
@@ -499,8 +507,8 @@ extern "C" size_t nnc_minmax_workspace_bytes(int64_t n)
     return (size_t)(cu_count() * 8 + 8) * sizeof(MinMaxPartial);
 }
 
-extern "C" int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev,
-                              void *ws, size_t ws_bytes, void *stream)
+static int minmax_impl(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev, int64_t *signs_dev,
+                       void *ws, size_t ws_bytes, void *stream)
 {
     if (n <= 0 || !x || !out_dev || !ws) return fail(NNC_EINVAL, "nnc_minmax_f32: bad argument (n must be > 0)");
     if (ws_bytes < nnc_minmax_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_minmax_f32: workspace too small");
@@ -510,9 +518,23 @@ extern "C" int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *
     if (vec) hipLaunchKernelGGL((k_minmax<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
     else hipLaunchKernelGGL((k_minmax<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
     LAUNCHCHK("k_minmax");
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, out_dev, reinterpret_cast<long long *>(count_dev));
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, out_dev, reinterpret_cast<long long *>(count_dev),
+                       reinterpret_cast<long long *>(signs_dev));
     LAUNCHCHK("k_minmax_final");
     return NNC_OK;
+}
+
+extern "C" int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev,
+                              void *ws, size_t ws_bytes, void *stream)
+{
+    return minmax_impl(x, n, skip_zeros, out_dev, count_dev, nullptr, ws, ws_bytes, stream);
+}
+
+extern "C" int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
+                                    void *stream)
+{
+    if (!signs_dev) return fail(NNC_EINVAL, "nnc_minmax_signs_f32: null signs_dev");
+    return minmax_impl(x, n, 0, out_dev, nullptr, signs_dev, ws, ws_bytes, stream);
 }
 
 // bin(x) = #{ steps[i] <= x } - 1 for non-decreasing steps (np.linspace is monotone), which is
@@ -647,6 +669,7 @@ struct KmTab {
     int32_t pad_[2];
     uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 31) << 11)
     double zl[NNC_KMAX], zr[NNC_KMAX]; // zone of every distinct centre: outside [zl, zr] (centred x) it cannot be the float32 arg-min
+    int32_t gc[NNC_KMAX], hc[NNC_KMAX]; // the same in cells (monotone): centre p can open cells <= gc[p], close cells >= hc[p]; k_cells turns them into cell[]
 };
 
 struct KmWs {
@@ -656,7 +679,8 @@ struct KmWs {
     int32_t glog2, rlog2;
     int32_t reloc_fail; // the windowed farthest-sample selection could not prove its result: redo it the long way
     float inv;         // cells per unit: cell = (int)((x~ - lo) * inv)
-    float pad1[3];
+    int32_t cells_pending; // k_finalize left new zones: k_cells has to rebuild tab[cur].cell
+    float pad1[2];
     float c[2][NNC_KMAX];        // centred centres in ORIGINAL index order; [cur] current, [cur^1] previous
     long long partials[2 * NNC_KMAX]; // sums then counts, original index order (all-reduced across ranks)
     long long partials_local[2 * NNC_KMAX]; // this rank's own sums/counts of the last accumulated iteration
@@ -993,9 +1017,11 @@ template <int MODE, bool VEC, typename LT, int ABL = 0, bool DIRECT = false>
 __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out,
-                                                       unsigned long long *__restrict__ dist_hist = nullptr)
+                                                       unsigned long long *__restrict__ dist_hist = nullptr,
+                                                       const int *__restrict__ n_dev = nullptr)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (MODE == 1 && n_dev) n = *n_dev; // label mode only: the real length lives on the device (the grid was sized for a bound)
     unsigned long long *trace = (MODE == 0) ? g_km_trace : nullptr;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (trace) tr0 = __builtin_amdgcn_s_memrealtime();
@@ -1018,6 +1044,7 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
     for (int j = 0; j < KM_RING; j++) r[j] = ld(s0 + j);
 
     if (MODE == 0 && (ws->st.done | ws->st.paused)) return;
+    if (MODE == 1 && n_dev && s0 >= s1 && blockIdx.x != gridDim.x - 1) return; // nothing in this workgroup's range
     const int k = ws->p.k;
     const int glog2 = ws->glog2, rlog2 = ws->rlog2;
     const int G = 1 << glog2;
@@ -1048,7 +1075,7 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
             orig_s[i] = tab->orig[i];
         }
         {
-            const int novf = tab->n_ovf;
+            const int novf = min(tab->n_ovf, KM_OVF_MAX);
             for (int i = threadIdx.x; i < novf; i += KM_THREADS) ovf_s[i] = tab->ovf[i];
         }
         if (MODE == 0 && !DIRECT) {
@@ -1250,6 +1277,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     unsigned long long *ftr = g_fin_trace;
 #define FSTAMP(i) do { if (ftr && tid == 0) ftr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     FSTAMP(0);
+    if (tid == 0) ws->cells_pending = 0;
     if (mode != FIN_INIT && mode != FIN_PACK_ONLY && ws->st.done) return;
     if (mode == FIN_FROM_SHARDS && ws->st.paused) return;
     if (mode == FIN_PACK_ONLY && (ws->st.done | ws->st.paused)) {
@@ -1390,7 +1418,27 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             }
         }
         still_sorted = __syncthreads_and(ok);
+        // nearly sorted (two neighbours changed places): a few odd-even transposition passes repair it
+        for (int pass = 0; pass < 3 && !still_sorted; pass++) {
+            for (int parity = 0; parity < 2; parity++) {
+                const int p = 2 * tid + parity;
+                if (p + 1 < k) {
+                    const float va = cs[p], vb = cs[p + 1];
+                    const uint16_t a = so[p], b = so[p + 1];
+                    if (!((va < vb) || (va == vb && a < b))) { cs[p] = vb; cs[p + 1] = va; so[p] = b; so[p + 1] = a; }
+                }
+                __syncthreads();
+            }
+            int ok2 = 1;
+            for (int p = tid; p + 1 < k; p += KM_THREADS) {
+                const float va = cs[p], vb = cs[p + 1];
+                ok2 &= (va < vb) || (va == vb && so[p] < so[p + 1]);
+            }
+            still_sorted = __syncthreads_and(ok2);
+        }
     }
+    FSTAMP(8);
+    if (ftr && tid == 0) ftr[13] = (unsigned long long)still_sorted;
     if (!still_sorted) {
         // rank by counting; PARTS lanes share one element and split the comparisons
         int parts = 1;
@@ -1403,6 +1451,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             if (j < k) {
                 v = cnew[j];
                 const int i0 = part * per_part, i1 = min(k, i0 + per_part);
+#pragma unroll 8
                 for (int i = i0; i < i1; i++) {
                     const float u = cnew[i];
                     rank += (u < v) || (u == v && i < j);
@@ -1413,6 +1462,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         }
     }
     __syncthreads();
+    FSTAMP(9);
     // Equal centres: the first one (lowest original index; the sort breaks ties that way) takes every
     // tie, the others can never win.  Keep only distinct values in the search tables.
     int ku = 0;
@@ -1441,6 +1491,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         }
         ku = carry;
     }
+    FSTAMP(10);
     for (int p = tid; p < ku; p += KM_THREADS) {
         const float v = cu[p];
         cs[p] = v;
@@ -1513,6 +1564,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             }
             gp_r[rd] = gp; hp_r[rd] = hp_;
         }
+        FSTAMP(11);
         // prefix max of G_p
         for (int rd = 0; rd < rounds; rd++) {
             const int p = rd * KM_THREADS + tid;
@@ -1559,42 +1611,57 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     }
     FSTAMP(5);
     FSTAMP(6);
-    // ---- cells
-    // first and last cells are open-ended: everything below lo / above hi is clamped into them
-    const int per = (G + KM_THREADS - 1) / KM_THREADS;
-    const int g0 = tid * per;
-    if (g0 < G) {
-        // plo(g) = first p with G_p >= g ; phi(g) = last p with H_p <= g  (both monotone in g)
-        int l = 0, h = ku - 1;
-        while (l < h) { int m = (l + h) >> 1; if (gcell[m] >= g0) h = m; else l = m + 1; }
-        int plo = l;
-        l = 0; h = ku - 1;
-        while (l < h) { int m = (l + h + 1) >> 1; if (hcell[m] <= g0) l = m; else h = m - 1; }
-        int phi = l;
-        int gnext = gcell[plo];                            // plo stays while g <= gnext
-        int hnext = (phi + 1 < ku) ? hcell[phi + 1] : G + 1; // phi advances once g >= hnext
-        for (int g = g0; g < g0 + per && g < G; g++) {
-            while (plo < ku - 1 && gnext < g) { plo++; gnext = gcell[plo]; }
-            while (phi < ku - 1 && hnext <= g) { phi++; hnext = (phi + 1 < ku) ? hcell[phi + 1] : G + 1; }
-            int lo_p = (g == 0) ? 0 : plo;       // below lo nothing exists, but keep cell 0 / G-1 conservative
-            int hi_p = (g == G - 1) ? ku - 1 : phi;
-            if (g == 0) { lo_p = 0; }
-            if (hi_p < lo_p) { lo_p = 0; hi_p = ku - 1; }
-            int c = hi_p - lo_p;
-            int field = lo_p;
-            if (c >= KM_CNT_SAT) {
-                c = KM_CNT_SAT;
-                const int idx = atomicAdd(&ovf_n, 1);
-                if (idx < KM_OVF_MAX) { tab->ovf[idx] = (unsigned)lo_p | ((unsigned)hi_p << 16); field = idx; }
-                else field = (int)KM_OVF_ALL;
-            }
-            tab->cell[g] = (uint16_t)(field | (c << KM_P_BITS));
-        }
-    }
-    __syncthreads();
-    if (tid == 0) tab->n_ovf = ovf_n < KM_OVF_MAX ? ovf_n : KM_OVF_MAX;
+    // ---- the cell table itself is built by k_cells (many workgroups: one CU is VALU-bound on it)
+    for (int p = tid; p < ku; p += KM_THREADS) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
+    if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = 1; }
     FSTAMP(7);
 #undef FSTAMP
+}
+
+// cell g -> candidate range [first p with gc[p] >= g, last p with hc[p] <= g] (both monotone in g);
+// one cell per thread.  The first and last cells are open-ended: everything below lo / above hi
+// is clamped into them.
+__global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws)
+{
+    __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX];
+    if (!ws->cells_pending) return;
+    const int G = 1 << ws->glog2;
+    const int g = blockIdx.x * KM_THREADS + threadIdx.x;
+    if ((int)(blockIdx.x * KM_THREADS) >= G) return;
+    KmTab *tab = &ws->tab[ws->cur];
+    const int ku = tab->ku;
+    for (int p = threadIdx.x; p < ku; p += KM_THREADS) { gcell[p] = tab->gc[p]; hcell[p] = tab->hc[p]; }
+    __syncthreads();
+    if (g >= G) return;
+    int l = 0, h = ku - 1;
+    while (l < h) { const int m = (l + h) >> 1; if (gcell[m] >= g) h = m; else l = m + 1; }
+    const int plo = l;
+    l = 0; h = ku - 1;
+    while (l < h) { const int m = (l + h + 1) >> 1; if (hcell[m] <= g) l = m; else h = m - 1; }
+    const int phi = l;
+    int lo_p = (g == 0) ? 0 : plo;       // below lo nothing exists, but keep cell 0 / G-1 conservative
+    int hi_p = (g == G - 1) ? ku - 1 : phi;
+    if (hi_p < lo_p) { lo_p = 0; hi_p = ku - 1; }
+    int c = hi_p - lo_p;
+    int field = lo_p;
+    if (c >= KM_CNT_SAT) {
+        c = KM_CNT_SAT;
+        const int idx = atomicAdd(&tab->n_ovf, 1); // readers clamp the count to KM_OVF_MAX
+        if (idx < KM_OVF_MAX) { tab->ovf[idx] = (unsigned)lo_p | ((unsigned)hi_p << 16); field = idx; }
+        else field = (int)KM_OVF_ALL;
+    }
+    tab->cell[g] = (uint16_t)(field | (c << KM_P_BITS));
+}
+
+static int km_launch_finalize(KmWs *w, int mode, int resume, void *stream)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, mode, resume);
+    LAUNCHCHK("k_finalize");
+    if (mode != FIN_PACK_ONLY) {
+        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w);
+        LAUNCHCHK("k_cells");
+    }
+    return NNC_OK;
 }
 
 static int km_check(void *ws, const nnc_kmeans_params *p, const char *who)
@@ -1613,7 +1680,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
         ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
-        ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0;
+        ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0; ws->cells_pending = 0;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
         float c = centers_init[j] - p.x_mean; // init -= X_mean (float32)
@@ -1643,9 +1710,7 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     hipLaunchKernelGGL(k_km_init, dim3(1), dim3(KM_THREADS), 0, S(stream), w, *p, glog2, rlog2, inv, centers_init_dev);
     LAUNCHCHK("k_km_init");
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, FIN_INIT, 0);
-    LAUNCHCHK("k_finalize(init)");
-    return NNC_OK;
+    return km_launch_finalize(w, FIN_INIT, 0, stream);
 }
 
 static int km_grid(int64_t n, size_t lds_bytes, bool one_per_cu = false)
@@ -1751,7 +1816,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     // command processor's arrival), so the difference is the launch's execution time
     hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
     hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
-#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr)
+#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr)
     const bool direct = (p->flags & 1) != 0; // caller promises long runs of equal cluster index (value-sorted input)
     if (vec && direct && g_ablation == 0) KM_LAUNCH_ACC(true, uint8_t, 0, true);
     else if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
@@ -1795,9 +1860,7 @@ extern "C" int nnc_kmeans_accumulate(const float *x, void *ws, const nnc_kmeans_
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, FIN_PACK_ONLY, 0);
-    LAUNCHCHK("k_finalize(pack)");
-    return NNC_OK;
+    return km_launch_finalize(w, FIN_PACK_ONLY, 0, stream);
 }
 
 extern "C" int64_t *nnc_kmeans_partials(void *ws)
@@ -1809,9 +1872,7 @@ extern "C" int64_t *nnc_kmeans_partials(void *ws)
 extern "C" int nnc_kmeans_finalize(void *ws, int resume, void *stream)
 {
     if (!ws) return fail(NNC_EINVAL, "nnc_kmeans_finalize: null workspace");
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), FIN_FROM_PARTIALS, resume ? 1 : 0);
-    LAUNCHCHK("k_finalize");
-    return NNC_OK;
+    return km_launch_finalize(reinterpret_cast<KmWs *>(ws), FIN_FROM_PARTIALS, resume ? 1 : 0, stream);
 }
 
 extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *stream)
@@ -1825,8 +1886,7 @@ extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_par
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, FIN_FROM_SHARDS, 0);
-        LAUNCHCHK("k_finalize(shards)");
+        if ((rc = km_launch_finalize(w, FIN_FROM_SHARDS, 0, stream))) return rc;
     }
     return NNC_OK;
 }
@@ -1864,9 +1924,9 @@ extern "C" int nnc_kmeans_get_centers(void *ws, int which, int centred, float *o
     return NNC_OK;
 }
 
-extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int which, void *labels_out,
-                                 int label_bytes, float *quant_out, float *dist_out, int64_t *dist_hist4096_dev,
-                                 void *stream)
+static int km_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int which, void *labels_out,
+                     int label_bytes, float *quant_out, float *dist_out, int64_t *dist_hist4096_dev,
+                     const int *n_dev, void *stream)
 {
     int rc = km_check(ws, pp, "nnc_kmeans_assign");
     if (rc) return rc;
@@ -1886,14 +1946,21 @@ extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_para
     unsigned long long *dh = reinterpret_cast<unsigned long long *>(dist_hist4096_dev);
     if (dh) HIPCHK(hipMemsetAsync(dh, 0, 4096 * sizeof(int64_t), S(stream)));
     if (label_bytes == 2) {
-        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh);
-        else hipLaunchKernelGGL((k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh);
+        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh, n_dev);
+        else hipLaunchKernelGGL((k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh, n_dev);
     } else {
-        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh);
-        else hipLaunchKernelGGL((k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh);
+        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh, n_dev);
+        else hipLaunchKernelGGL((k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh, n_dev);
     }
     LAUNCHCHK("k_assign<labels>");
     return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int which, void *labels_out,
+                                 int label_bytes, float *quant_out, float *dist_out, int64_t *dist_hist4096_dev,
+                                 void *stream)
+{
+    return km_assign(x, ws, pp, which, labels_out, label_bytes, quant_out, dist_out, dist_hist4096_dev, nullptr, stream);
 }
 
 
@@ -2102,6 +2169,7 @@ __device__ __forceinline__ void block_scan2(long long &a0, long long &a1, long l
 
 #define KM_RELOC_WMAX 8192 // a window side never grows beyond this many samples
 #define KM_SURV_MAX 2048   // survivors of the histogram cut that are ranked exactly
+#define KM_SURV_SMALL 384  // ... the cut is refined while there are more than this many
 
 // one workgroup: the window table.  meta = {n_cand, n_windows, bad, window}
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, const KmWs *__restrict__ ws,
@@ -2167,20 +2235,21 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__res
     }
 }
 
-// the candidates themselves (any grid): one wave per window, the unused tail of cand_x is zeroed
+// the candidates themselves (any grid): one wave per window
 __global__ __launch_bounds__(256) void k_reloc_fill(const float *__restrict__ xs, const KmWin *__restrict__ win,
                                                     const int *__restrict__ meta, float *__restrict__ cand_x, long long cap)
 {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), nwaves = (int)((gridDim.x * blockDim.x) >> 6);
-    const int nwin = meta[1], total = meta[0];
+    const int nwin = meta[1];
+    const long long total = meta[0];
     if (!meta[2])
         for (int j = wave; j < nwin; j += nwaves) {
             const KmWin w = win[j];
             for (int i = lane; i < w.len; i += 64) cand_x[w.off + i] = xs[w.start + i];
         }
-    const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (long long i = total + tid; i < cap; i += (long long)gridDim.x * blockDim.x) cand_x[i] = 0.0f;
+    // up to three scalars after the last candidate are read as part of a float4 by the distance pass
+    if (blockIdx.x == 0 && threadIdx.x < 4 && total + threadIdx.x < cap) cand_x[total + threadIdx.x] = 0.0f;
 }
 
 // One workgroup: the n_empty largest keys among the candidates (histogram cut on the distance
@@ -2219,24 +2288,33 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         __syncthreads();
         const unsigned NOBIN = 0xFFFFu;
         auto bin_of = [&](unsigned u) -> unsigned { return (pshift < 0 || (u >> pshift) == prefix) ? ((u >> shift) & mask) : NOBIN; };
-        for (int v0 = 0; v0 < nvec; v0 += KM_THREADS) { // wave-uniform trip count
-            const int v = v0 + tid;
-            const bool have = v < nvec;
-            const uint4 q = have ? d4[v] : make_uint4(0u, 0u, 0u, 0u);
-            const unsigned b0 = have ? bin_of(q.x) : NOBIN, b1 = have ? bin_of(q.y) : NOBIN;
-            const unsigned b2 = have ? bin_of(q.z) : NOBIN, b3 = have ? bin_of(q.w) : NOBIN;
-            const unsigned long long act = __ballot(have);
-            if (!act) continue;
-            const unsigned first = (unsigned)__shfl((int)b0, __ffsll((long long)act) - 1);
-            const bool same = !have || (b0 == first && b1 == first && b2 == first && b3 == first);
-            if (__all(same)) {
-                if (first != NOBIN && lane == 0) atomicAdd(&hist[first], 4u * (unsigned)__popcll(act));
-            } else if (have) {
-                unsigned rb = b0, rc = 1;
-                if (b1 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b1; rc = 1; }
-                if (b2 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b2; rc = 1; }
-                if (b3 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b3; rc = 1; }
-                if (rb != NOBIN) atomicAdd(&hist[rb], rc);
+        for (int v0 = 0; v0 < nvec; v0 += 8 * KM_THREADS) { // wave-uniform trip count; eight loads in flight per thread
+            uint4 qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int v = v0 + u * KM_THREADS + tid;
+                qv[u] = v < nvec ? d4[v] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int v = v0 + u * KM_THREADS + tid;
+                const bool have = v < nvec;
+                const uint4 q = qv[u];
+                const unsigned b0 = have ? bin_of(q.x) : NOBIN, b1 = have ? bin_of(q.y) : NOBIN;
+                const unsigned b2 = have ? bin_of(q.z) : NOBIN, b3 = have ? bin_of(q.w) : NOBIN;
+                const unsigned long long act = __ballot(have);
+                if (!act) continue;
+                const unsigned first = (unsigned)__shfl((int)b0, __ffsll((long long)act) - 1);
+                const bool same = !have || (b0 == first && b1 == first && b2 == first && b3 == first);
+                if (__all(same)) {
+                    if (first != NOBIN && lane == 0) atomicAdd(&hist[first], 4u * (unsigned)__popcll(act));
+                } else if (have) {
+                    unsigned rb = b0, rc = 1;
+                    if (b1 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b1; rc = 1; }
+                    if (b2 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b2; rc = 1; }
+                    if (b3 == rb) rc++; else { if (rb != NOBIN) atomicAdd(&hist[rb], rc); rb = b3; rc = 1; }
+                    if (rb != NOBIN) atomicAdd(&hist[rb], rc);
+                }
             }
         }
         for (int i = (nvec << 2) + tid; i < n_cand; i += KM_THREADS) {
@@ -2267,7 +2345,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         total_ge = s_ge;
         thr = prefix << shift;
         __syncthreads();
-        if (total_ge <= KM_SURV_MAX) break;
+        if (total_ge <= KM_SURV_SMALL) break;
     }
     int bad = 0;
     if (total_ge > KM_SURV_MAX) bad |= 128; // a crowd of exactly equal distances at the cut
@@ -2281,9 +2359,18 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
                 if (slot < KM_SURV_MAX) surv[slot] = ((unsigned long long)u << 32) | (unsigned long long)f32_ordered_bits(cand_x[i]);
             }
         };
-        for (int v = tid; v < nvec; v += KM_THREADS) {
-            const uint4 q = d4[v];
-            take(q.x, 4 * v); take(q.y, 4 * v + 1); take(q.z, 4 * v + 2); take(q.w, 4 * v + 3);
+        for (int v0 = 0; v0 < nvec; v0 += 8 * KM_THREADS) {
+            uint4 qv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int v = v0 + u * KM_THREADS + tid;
+                qv[u] = v < nvec ? d4[v] : make_uint4(0u, 0u, 0u, 0u);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int v = v0 + u * KM_THREADS + tid;
+                if (v < nvec) { take(qv[u].x, 4 * v); take(qv[u].y, 4 * v + 1); take(qv[u].z, 4 * v + 2); take(qv[u].w, 4 * v + 3); }
+            }
         }
         for (int i = (nvec << 2) + tid; i < n_cand; i += KM_THREADS) take(__float_as_uint(cand_d[i]), i);
     }
@@ -2291,19 +2378,32 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     const int m = min(s_nsurv, KM_SURV_MAX);
     if (!bad && m < n_empty) bad |= 2;
     if (!bad) {
-        // bitonic sort, descending, of the survivors (padded with zeros to a power of two)
-        int M = 2;
-        while (M < m) M <<= 1;
-        for (int size = 2; size <= M; size <<= 1)
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                __syncthreads();
-                for (int t = tid; t < (M >> 1); t += KM_THREADS) {
-                    const int lo_i = 2 * t - (t & (stride - 1)), hi_i = lo_i + stride;
-                    const bool up = (lo_i & size) == 0;
-                    const unsigned long long ka = surv[lo_i], kb = surv[hi_i];
-                    if ((ka < kb) == up) { surv[lo_i] = kb; surv[hi_i] = ka; }
-                }
+        if (m <= KM_SURV_SMALL) {
+            // few survivors: rank by counting (ties cannot matter: equal keys are interchangeable)
+            unsigned long long mine = 0ull;
+            int r = -1;
+            if (tid < m) {
+                mine = surv[tid];
+                r = 0;
+                for (int j = 0; j < m; j++) { const unsigned long long kj = surv[j]; r += (kj > mine) || (kj == mine && j < tid); }
             }
+            __syncthreads();
+            if (r >= 0) surv[r] = mine;
+        } else {
+            // bitonic sort, descending, of the survivors (padded with zeros to a power of two)
+            int M = 2;
+            while (M < m) M <<= 1;
+            for (int size = 2; size <= M; size <<= 1)
+                for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                    __syncthreads();
+                    for (int t = tid; t < (M >> 1); t += KM_THREADS) {
+                        const int lo_i = 2 * t - (t & (stride - 1)), hi_i = lo_i + stride;
+                        const bool up = (lo_i & size) == 0;
+                        const unsigned long long ka = surv[lo_i], kb = surv[hi_i];
+                        if ((ka < kb) == up) { surv[lo_i] = kb; surv[hi_i] = ka; }
+                    }
+                }
+        }
         __syncthreads();
         for (int r = tid; r < n_empty; r += KM_THREADS) keys_out[r] = (long long)surv[r];
     }
@@ -2382,6 +2482,53 @@ extern "C" int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, co
                        reinterpret_cast<long long *>(keys_out_dev));
     LAUNCHCHK("k_reloc_select");
     return NNC_OK;
+}
+
+// The whole windowed relocation as one call: windows -> candidates -> exact distances -> selection
+// + proof + relocation -> resumed finalize.  No host read; the outcome shows in the next status.
+static size_t reloc_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" int32_t nnc_kmeans_reloc_window(int64_t n, int32_t n_empty)
+{
+    int64_t w = 64;
+    while (w < n_empty) w *= 2;
+    if (n_empty < 1 || w > 1024 || 2 * w > n) return 0; // not applicable: use the full pass
+    return (int32_t)w;
+}
+
+static int64_t reloc_cap(int32_t k, int32_t window) { return 8 * (int64_t)window * (k + 1); } // sides double where two centres are close
+
+extern "C" size_t nnc_kmeans_reloc_scratch_bytes(int32_t k, int32_t window)
+{
+    if (k < 1 || window < 1) return 0;
+    const size_t cap = (size_t)reloc_cap(k, window);
+    return 2 * reloc_align(cap * 4) + reloc_align(16 * (size_t)(k + 2)) + reloc_align(16) + reloc_align(8 * (size_t)NNC_KMAX);
+}
+
+extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
+                                            void *scratch_dev, size_t scratch_bytes, void *stream)
+{
+    int rc = km_check(ws, p, "nnc_kmeans_relocate_windowed");
+    if (rc) return rc;
+    const int32_t window = nnc_kmeans_reloc_window(p->n, n_empty);
+    if (window == 0) return fail(NNC_EINVAL, "nnc_kmeans_relocate_windowed: not applicable (nnc_kmeans_reloc_window() == 0)");
+    if (!x_sorted || !scratch_dev || (reinterpret_cast<uintptr_t>(scratch_dev) & 255) != 0)
+        return fail(NNC_EINVAL, "nnc_kmeans_relocate_windowed: null or unaligned (256 B) pointer");
+    if (scratch_bytes < nnc_kmeans_reloc_scratch_bytes(p->k, window)) return fail(NNC_ENOSPACE, "nnc_kmeans_relocate_windowed: scratch too small");
+    const int64_t cap = reloc_cap(p->k, window);
+    unsigned char *b = reinterpret_cast<unsigned char *>(scratch_dev);
+    float *cand_x = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
+    float *cand_d = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
+    void *win = b; b += reloc_align(16 * (size_t)(p->k + 2));
+    int32_t *meta = reinterpret_cast<int32_t *>(b); b += reloc_align(16);
+    int64_t *keys = reinterpret_cast<int64_t *>(b);
+    if ((rc = nnc_kmeans_reloc_candidates(x_sorted, ws, p, window, cand_x, cap, win, meta, stream))) return rc;
+    nnc_kmeans_params pc = *p;
+    pc.n = cap;
+    pc.n_total = std::max<int64_t>(cap, p->n_total);
+    if ((rc = km_assign(cand_x, ws, &pc, 0, nullptr, 1, nullptr, cand_d, nullptr, meta, stream))) return rc; // meta[0] = n_cand
+    if ((rc = nnc_kmeans_relocate_checked(ws, cand_x, cand_d, win, meta, n_empty, keys, stream))) return rc;
+    return nnc_kmeans_finalize(ws, 1, stream);
 }
 
 // flag = 1 if the two label vectors are identical, else 0

@@ -8,6 +8,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <algorithm>
 #include <string>
 
 #include "nnc.h"
@@ -34,5 +35,147 @@ extern "C" int nnc_sort_f32(const float *x, int64_t n, float *sorted_out, void *
     if (!ws || ws_bytes < need) return nnc_set_error_(NNC_ENOSPACE, "nnc_sort_f32: workspace too small");
     e = rocprim::radix_sort_keys(ws, need, x, sorted_out, (size_t)n, 0, 32, reinterpret_cast<hipStream_t>(stream));
     if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    return NNC_OK;
+}
+
+// --------------------------------------------------------------------------------------
+// The same for a PRUNED vector: most weights are exact zeros, which need no sorting.  One
+// three-way partition (negatives / positives / zeros dropped), two radix sorts of the non-zero
+// parts straight into their places, zeros filled in between.  The counts come from
+// nnc_minmax_signs_f32 (the fit set-up reads them together with min / max).  -0.0 counts as a
+// zero and comes back as +0.0: equal as a value, which is all the iterations look at.
+// --------------------------------------------------------------------------------------
+// negatives -> t_neg[], positives (and NaN) -> t_pos[], zeros dropped; any order within a part.
+// Tiles of 16384 weights; one packed 64-bit atomic per tile hands out both output ranges.
+#define SPLIT_THREADS 1024
+__global__ __launch_bounds__(SPLIT_THREADS) void k_split_signs(const float *__restrict__ x, long long n, float *__restrict__ t_neg,
+                                                               float *__restrict__ t_pos, unsigned long long *__restrict__ counter,
+                                                               long long cap_neg, long long cap_pos)
+{
+    __shared__ unsigned wave_tot[SPLIT_THREADS / 64];
+    __shared__ unsigned long long base_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    const long long nvec = vec ? (n >> 2) : 0;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    const long long ntiles = (nvec + 4 * SPLIT_THREADS - 1) / (4 * SPLIT_THREADS);
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        float4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const long long v = t * (4 * SPLIT_THREADS) + (long long)j * SPLIT_THREADS + tid;
+            q[j] = v < nvec ? x4[v] : make_float4(0.f, 0.f, 0.f, 0.f); // padding zeros are dropped like any zero
+        }
+        unsigned c = 0; // negatives | positives << 16
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float e[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) c += (e[i] < 0.0f) ? 1u : ((e[i] == 0.0f) ? 0u : 0x10000u);
+        }
+        unsigned sc = c;
+        for (int off = 1; off < 64; off <<= 1) { const unsigned o = __shfl_up(sc, off); if (lane >= off) sc += o; }
+        if (lane == 63) wave_tot[wv] = sc;
+        __syncthreads();
+        unsigned pre = 0, tot = 0;
+        for (int w = 0; w < SPLIT_THREADS / 64; w++) { const unsigned o = wave_tot[w]; if (w < wv) pre += o; tot += o; }
+        if (tid == 0) base_s = atomicAdd(counter, (unsigned long long)(tot & 0xFFFFu) | ((unsigned long long)(tot >> 16) << 32));
+        __syncthreads();
+        const unsigned long long base = base_s;
+        const unsigned excl = pre + sc - c;
+        long long on = (long long)(base & 0xFFFFFFFFull) + (excl & 0xFFFFu);
+        long long op = (long long)(base >> 32) + (excl >> 16);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float e[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                // (bounds: the counts are the caller's; wrong ones must not fault)
+                if (e[i] < 0.0f) { if (on < cap_neg) t_neg[on] = e[i]; on++; }
+                else if (!(e[i] == 0.0f)) { if (op < cap_pos) t_pos[op] = e[i]; op++; }
+            }
+        }
+        __syncthreads(); // base_s / wave_tot are reused by the next tile
+    }
+    // the scalars after the last float4 (the whole vector if it is not 16-byte aligned): first workgroup, one by one
+    if (blockIdx.x == 0) {
+        for (long long i0 = nvec << 2; i0 < n; i0 += SPLIT_THREADS) {
+            const long long i = i0 + tid;
+            const float e = i < n ? x[i] : 0.0f;
+            const bool ng = e < 0.0f, ps = !(e < 0.0f) && !(e == 0.0f);
+            const unsigned long long bn = __ballot(ng), bp = __ballot(ps);
+            unsigned long long base = 0;
+            if (lane == 0 && (bn | bp)) base = atomicAdd(counter, (unsigned long long)__popcll(bn) | ((unsigned long long)__popcll(bp) << 32));
+            base = __shfl(base, 0);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const long long in_ = (long long)(base & 0xFFFFFFFFull) + __popcll(bn & below), ip_ = (long long)(base >> 32) + __popcll(bp & below);
+            if (ng && in_ < cap_neg) t_neg[in_] = e;
+            if (ps && ip_ < cap_pos) t_pos[ip_] = e;
+        }
+    }
+}
+
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+static hipError_t pruned_sizes(int64_t n_neg, int64_t n_pos, size_t *sort_bytes)
+{
+    size_t sa = 0, sb = 0;
+    hipError_t e;
+    if (n_neg > 0 && (e = rocprim::radix_sort_keys(nullptr, sa, (const float *)nullptr, (float *)nullptr, (size_t)n_neg)) != hipSuccess) return e;
+    if (n_pos > 0 && (e = rocprim::radix_sort_keys(nullptr, sb, (const float *)nullptr, (float *)nullptr, (size_t)n_pos)) != hipSuccess) return e;
+    *sort_bytes = sa > sb ? sa : sb;
+    return hipSuccess;
+}
+
+extern "C" size_t nnc_sort_pruned_workspace_bytes(int64_t n, int64_t n_neg, int64_t n_zero)
+{
+    if (n <= 0 || n_neg < 0 || n_zero < 0 || n_neg + n_zero > n) return 0;
+    const int64_t n_pos = n - n_neg - n_zero;
+    size_t sb = 0;
+    if (pruned_sizes(n_neg, n_pos, &sb) != hipSuccess) return 0;
+    return al256((size_t)(n_neg + n_pos) * 4 + 16) + al256(sizeof(unsigned long long)) + al256(sb) + 256;
+}
+
+extern "C" int nnc_sort_pruned_f32(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float *sorted_out, void *ws,
+                                   size_t ws_bytes, void *stream)
+{
+    if (n < 0 || n_neg < 0 || n_zero < 0 || n_neg + n_zero > n || n >= ((int64_t)1 << 32) || (n > 0 && (!x || !sorted_out)))
+        return nnc_set_error_(NNC_EINVAL, "nnc_sort_pruned_f32: bad argument");
+    if (n == 0) return NNC_OK;
+    const int64_t n_pos = n - n_neg - n_zero;
+    size_t sb = 0;
+    hipError_t e = pruned_sizes(n_neg, n_pos, &sb);
+    if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    if (!ws || ws_bytes < nnc_sort_pruned_workspace_bytes(n, n_neg, n_zero)) return nnc_set_error_(NNC_ENOSPACE, "nnc_sort_pruned_f32: workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    unsigned char *b = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
+    float *t_neg = reinterpret_cast<float *>(b);
+    float *t_pos = t_neg + n_neg;
+    b += al256((size_t)(n_neg + n_pos) * 4 + 16);
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(b); b += al256(sizeof(unsigned long long));
+    void *stemp = b;
+    e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    {
+        const long long tiles = (n / 4 + 4 * SPLIT_THREADS - 1) / (4 * SPLIT_THREADS);
+        int grid = (int)std::min<long long>(std::max<long long>(tiles, 1), 512);
+        hipLaunchKernelGGL(k_split_signs, dim3(grid), dim3(SPLIT_THREADS), 0, s, x, (long long)n, t_neg, t_pos, counter, (long long)n_neg, (long long)n_pos);
+        e = hipGetLastError();
+        if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    }
+    if (n_neg > 0) {
+        size_t need = sb;
+        e = rocprim::radix_sort_keys(stemp, need, (const float *)t_neg, sorted_out, (size_t)n_neg, 0, 32, s);
+        if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    }
+    if (n_zero > 0) {
+        e = hipMemsetAsync(sorted_out + n_neg, 0, (size_t)n_zero * 4, s);
+        if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    }
+    if (n_pos > 0) {
+        size_t need = sb;
+        e = rocprim::radix_sort_keys(stemp, need, (const float *)t_pos, sorted_out + n_neg + n_zero, (size_t)n_pos, 0, 32, s);
+        if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    }
     return NNC_OK;
 }

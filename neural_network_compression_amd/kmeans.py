@@ -100,13 +100,22 @@ class DeviceKMeans:
 
         # ---- NumPy-exact mean / var, min / max  (one host sync for the whole fit set-up)
         mean_d, var_d, _ = ops.moments(x, n_total, group)
-        mm, _ = ops.minmax(x) if n > 0 else (torch.tensor([np.inf, -np.inf], dtype=torch.float32, device=self.dev), None)
+        if n > 0:
+            mm, signs = ops.minmax_signs(x)   # this rank's own counts of negative / zero weights: for the sort below
+        else:
+            mm = torch.tensor([np.inf, -np.inf], dtype=torch.float32, device=self.dev)
+            signs = torch.zeros(2, dtype=torch.int64, device=self.dev)
         if group is not None:
             from . import sharding
 
             mm = sharding.allreduce_minmax(mm, group)
-        host = torch.cat([mean_d, var_d, mm]).cpu().numpy()
-        mean, var, xmin, xmax = (np.float32(v) for v in host)
+        pin_f = torch.empty(4, dtype=torch.float32, pin_memory=True)
+        pin_i = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        pin_f.copy_(torch.cat([mean_d, var_d, mm]), non_blocking=True)
+        pin_i.copy_(signs, non_blocking=True)
+        torch.cuda.current_stream(self.dev).synchronize()
+        mean, var, xmin, xmax = (np.float32(v) for v in pin_f.numpy())
+        self.n_negative, self.n_zero = (int(v) for v in pin_i.numpy())
         self.x_mean = mean
         self.tol_ = np.float32(var * np.float32(tol))  # np.mean(np.var(X, axis=0)) * tol, float32
         lo, hi = np.float32(xmin - mean), np.float32(xmax - mean)  # exact range of the centred data
@@ -127,6 +136,7 @@ class DeviceKMeans:
         self.n_relocations = 0
         self.n_reloc_windowed = 0   # relocation events settled by the windowed selection
         self.n_reloc_full = 0       # ... by the full distance pass
+        self._reloc_scratch = None
         if reloc not in ("auto", "full"):
             raise ValueError("reloc must be 'auto' or 'full'")
         self.reloc = reloc
@@ -146,6 +156,13 @@ class DeviceKMeans:
 
     def _sorted_copy(self, x: torch.Tensor) -> torch.Tensor:
         out = torch.empty_like(x)
+        if 4 * self.n_zero >= x.numel():
+            # pruned tensor: partition the zeros out, sort only the rest
+            ws_bytes = self.L.nnc_sort_pruned_workspace_bytes(x.numel(), self.n_negative, self.n_zero)
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
+            nat.check(self.L.nnc_sort_pruned_f32(x.data_ptr(), x.numel(), self.n_negative, self.n_zero, out.data_ptr(),
+                                                 ws.data_ptr(), ws_bytes, self.stream))
+            return out
         ws_bytes = self.L.nnc_sort_workspace_bytes(x.numel())
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
         nat.check(self.L.nnc_sort_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws_bytes, self.stream))
@@ -235,36 +252,19 @@ class DeviceKMeans:
         key = (d.view(torch.int32).to(torch.int64) << 32) | ordered
         return torch.topk(key, m, largest=True, sorted=True).values
 
-    RELOC_WINDOW_MIN = 64
-    RELOC_WINDOW_MAX = 1024
-
     def _relocate_windowed(self, n_empty: int) -> bool:
-        """The same relocation from 2 * window * (k + 1) candidates around the cluster boundaries of
-        the value-sorted vector (include/nnc.h, nnc_kmeans_reloc_candidates): no pass over the
+        """The same relocation from windows of candidates around the cluster boundaries of the
+        value-sorted vector (include/nnc.h, nnc_kmeans_relocate_windowed): no pass over the
         vector, no host read.  The device proves the selection; if it cannot, the resumed finalize
         leaves status.paused = 2 and the caller comes back through the full pass."""
-        window = self.RELOC_WINDOW_MIN
-        while window < n_empty:
-            window *= 2
-        if window > self.RELOC_WINDOW_MAX or 2 * window > self.n:
+        window = int(self.L.nnc_kmeans_reloc_window(self.n, n_empty))
+        if window == 0:
             return False
-        cap = 8 * window * (self.k + 1)   # window sides double where two centres are close (wide open zone)
-        cand = torch.empty(cap, dtype=torch.float32, device=self.dev)
-        dist = torch.empty(cap, dtype=torch.float32, device=self.dev)
-        win = torch.empty(16 * (self.k + 2), dtype=torch.uint8, device=self.dev)
-        meta = torch.empty(4, dtype=torch.int32, device=self.dev)
-        keys = torch.empty(n_empty, dtype=torch.int64, device=self.dev)
-        ws = self.ws.data_ptr()
-        nat.check(self.L.nnc_kmeans_reloc_candidates(self.x_iter.data_ptr(), ws, ctypes.byref(self.p), window, cand.data_ptr(), cap,
-                                                     win.data_ptr(), meta.data_ptr(), self.stream))
-        pc = nat.KMeansParams.from_buffer_copy(self.p)
-        pc.n = cap
-        pc.n_total = max(cap, int(self.p.n_total))
-        nat.check(self.L.nnc_kmeans_assign(cand.data_ptr(), ws, ctypes.byref(pc), 0, None, 1, None, dist.data_ptr(), None, self.stream))
-        nat.check(self.L.nnc_kmeans_relocate_checked(ws, cand.data_ptr(), dist.data_ptr(), win.data_ptr(), meta.data_ptr(),
-                                                     n_empty, keys.data_ptr(), self.stream))
-        nat.check(self.L.nnc_kmeans_finalize(ws, 1, self.stream))
-        self._reloc_meta = meta   # {n_cand, n_windows, bad, window}: diagnostics (tools/debug_reloc.py)
+        need = int(self.L.nnc_kmeans_reloc_scratch_bytes(self.k, window))
+        if self._reloc_scratch is None or self._reloc_scratch.numel() < need:
+            self._reloc_scratch = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        nat.check(self.L.nnc_kmeans_relocate_windowed(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), n_empty,
+                                                      self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(), self.stream))
         return True
 
     def _relocate_and_resume(self, st) -> None:

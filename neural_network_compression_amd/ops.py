@@ -142,6 +142,20 @@ def minmax(x: torch.Tensor, skip_zeros: bool = False):
     return out, cnt
 
 
+def minmax_signs(x: torch.Tensor):
+    """(float32[2] = {min, max}, int64[2] = {#negative, #zero}) on the device, one pass."""
+    _require_cuda(x, "x", torch.float32)
+    if x.numel() == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    L = nat.load()
+    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    signs = torch.empty(2, dtype=torch.int64, device=x.device)
+    ws_bytes = L.nnc_minmax_workspace_bytes(x.numel())
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    nat.check(L.nnc_minmax_signs_f32(_ptr(x), x.numel(), _ptr(out), _ptr(signs), _ptr(ws), ws_bytes, _stream(x)))
+    return out, signs
+
+
 def hist31(x: torch.Tensor, steps: torch.Tensor, skip_zeros: bool = False) -> torch.Tensor:
     """int64[31] counts of steps[b] <= x < steps[b+1] (steps: device float32[32])."""
     _require_cuda(x, "x", torch.float32)

@@ -20,6 +20,6 @@ for it in range(60):
         r = ctypes.c_int32(0)
         nat.check(L.nnc_debug_reloc_fail(km.ws.data_ptr(), ctypes.byref(r)))
         st2 = km.status()
-        print(f"iter {st.iter} n_empty {ne} same_counts {st.same_counts}: fail bits {r.value} paused {st2.paused} meta {km._reloc_meta.cpu().tolist()} k_distinct?")
+        print(f"iter {st.iter} n_empty {ne} same_counts {st.same_counts}: fail bits {r.value} paused {st2.paused}")
         if st2.paused:
             km._relocate_and_resume(st2)

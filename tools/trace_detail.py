@@ -43,6 +43,11 @@ for it in range(1, max(which_iters) + 1):
         print("  epilogue ", pct(rel[:, 3] - rel[:, 2]))
         print("  loop end ", pct(rel[:, 2]))
         print("  end      ", pct(rel[:, 3]))
+        f = (tr.cpu().numpy()[4 * 1024: 4 * 1024 + 13] - tr.cpu().numpy()[4 * 1024]) * 0.01
+        order = [(0, "start"), (1, "shards->partials"), (2, "empties+average"), (3, "shift+tol+state"), (8, "still-sorted test"), (9, "rank sort"),
+                 (10, "distinct"), (4, "tables written"), (11, "zones raw"), (5, "zone scans"), (12, "cell binary search"), (7, "cells")]
+        print("  still_sorted flag:", int(tr.cpu().numpy()[4 * 1024 + 13]))
+        print("  k_finalize stamps (us since start): " + ", ".join(f"{nm} {f[i]:.2f}" for i, nm in order))
         for xcd in range(8):
             m = (idx % 8) == xcd
             print(f"   xcd {xcd}: start med {np.median(rel[m,0]):5.2f} loop med {np.median(rel[m,2]-rel[m,1]):5.2f} loop-end med/max {np.median(rel[m,2]):5.2f}/{rel[m,2].max():5.2f}")
