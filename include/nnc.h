@@ -189,6 +189,11 @@ int nnc_kmeans_finalize(void *ws, int resume, void *stream);
 int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *p, int32_t iters, void *stream);
 /* Asynchronous copy of the status block to host_out (pinned or pageable host memory). */
 int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, void *stream);
+/* The same without a copy command and a stream synchronisation: a one-thread kernel writes the
+ * status block to host_mapped (host memory the device can write: hipHostMalloc / pinned, 8-byte
+ * aligned, sizeof(nnc_kmeans_status) + 8 bytes) and then `ticket` into the 8 bytes behind it;
+ * the host polls that word until it reads its ticket, then reads the status. */
+int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t ticket, void *stream);
 int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream);
 /* which: 0 = current centres (used by the next E-step), 1 = centres of the previous E-step.
  * centred != 0: as stored (x_mean subtracted); else un-centred (+ x_mean, float32 add). */

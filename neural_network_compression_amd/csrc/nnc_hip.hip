@@ -1898,6 +1898,26 @@ extern "C" int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, vo
     return NNC_OK;
 }
 
+// the status block straight into host memory the device can write (pinned / hipHostMalloc), then the ticket: the
+// host spins on the ticket instead of paying a copy command plus a stream synchronisation
+__global__ void k_publish_status(const KmWs *ws, nnc_kmeans_status *host_st, unsigned long long *host_ticket, unsigned long long ticket)
+{
+    *host_st = ws->st;
+    __threadfence_system();
+    *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
+}
+
+extern "C" int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t ticket, void *stream)
+{
+    if (!ws || !host_mapped || (reinterpret_cast<uintptr_t>(host_mapped) & 7) != 0) return fail(NNC_EINVAL, "nnc_kmeans_status_publish: null or unaligned pointer");
+    unsigned char *b = reinterpret_cast<unsigned char *>(host_mapped);
+    hipLaunchKernelGGL(k_publish_status, dim3(1), dim3(1), 0, S(stream), reinterpret_cast<const KmWs *>(ws),
+                       reinterpret_cast<nnc_kmeans_status *>(b), reinterpret_cast<unsigned long long *>(b + sizeof(nnc_kmeans_status)),
+                       (unsigned long long)ticket);
+    LAUNCHCHK("k_publish_status");
+    return NNC_OK;
+}
+
 __global__ void k_set_done(KmWs *ws, int code) { ws->st.done = code; }
 
 extern "C" int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream)
