@@ -108,8 +108,10 @@ size_t nnc_minmax_workspace_bytes(int64_t n);
 int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev, void *ws,
                    size_t ws_bytes, void *stream);
 
-/* min / max over all elements plus signs_dev[0] = #{x < 0}, signs_dev[1] = #{x == 0}: what
- * nnc_sort_pruned_f32 needs, from the pass the k-means set-up makes anyway. */
+/* One pass for everything the pipeline wants to know about a (pruned) vector: out_dev[0..1] =
+ * min / max over all elements, out_dev[2..3] = min / max over the non-zero ones (+inf / -inf if
+ * there are none), signs_dev[0] = #{x < 0}, signs_dev[1] = #{x == 0} (what nnc_sort_pruned_f32
+ * needs).  out_dev holds 4 floats. */
 int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
                          void *stream);
 

@@ -231,33 +231,33 @@ extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const fl
     return NNC_OK;
 }
 
-// Sequential float32 fold of the chunk sums (NumPy's order) by one thread; the other 1023
-// stage the next tile into LDS.
+// Sequential float32 fold of the chunk sums (NumPy's order).  The chain of dependent adds is the
+// whole cost (one add per chunk sum, nothing to parallelise); one lane runs it out of LDS with
+// 16-byte reads issued well ahead, the others stage the next tile.
 #define FOLD_TILE 8192
 __global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks, int64_t nchunks, int64_t count,
                                                int op, const float *__restrict__ scale_dev,
                                                float *__restrict__ out)
 {
-    __shared__ float buf[FOLD_TILE];
-    float acc = 0.0f; // the running fold lives in every lane of wave 0 (uniform)
+    __shared__ __align__(16) float buf[FOLD_TILE];
+    float acc = 0.0f;
     for (int64_t base = 0; base < nchunks; base += FOLD_TILE) {
         int len = (int)((nchunks - base) < FOLD_TILE ? (nchunks - base) : FOLD_TILE);
         for (int i = threadIdx.x; i < len; i += 1024) buf[i] = chunks[base + i];
         __syncthreads();
-        if (threadIdx.x < 64) {
-            // wave 0: each lane holds one value per 64-block; v_readlane feeds the sequential chain,
-            // so the only dependent instruction per element is the float32 add
-            for (int b = 0; b < len; b += 64) {
-                const int idx = b + (int)threadIdx.x;
-                const float v = idx < len ? buf[idx] : 0.0f;
-                const int m = (len - b) < 64 ? (len - b) : 64;
-                if (m == 64) {
+        if (threadIdx.x == 0) {
+            const float4 *b4 = reinterpret_cast<const float4 *>(buf);
+            const int nq = len >> 2;
+            int qd = 0;
+            for (; qd + 8 <= nq; qd += 8) {
+                float4 v[8];
 #pragma unroll
-                    for (int j = 0; j < 64; j++) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-                } else {
-                    for (int j = 0; j < m; j++) acc = acc + __shfl(v, j);
-                }
+                for (int u = 0; u < 8; u++) v[u] = b4[qd + u];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { acc = acc + v[u].x; acc = acc + v[u].y; acc = acc + v[u].z; acc = acc + v[u].w; }
             }
+            for (; qd < nq; qd++) { const float4 v = b4[qd]; acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w; }
+            for (int i = nq << 2; i < len; i++) acc = acc + buf[i];
         }
         __syncthreads();
     }
@@ -429,19 +429,20 @@ extern "C" int nnc_apply_mask_f32(float *x, const uint8_t *mask, int64_t n, void
 // ======================================================================================
 // 3. min / max / count, 31-bin histogram, bincount
 // ======================================================================================
-struct MinMaxPartial { float mn, mx; unsigned long long cnt; unsigned long long neg, zer; };
+struct MinMaxPartial { float mn, mx; unsigned long long cnt; unsigned long long neg, zer; float mn_nz, mx_nz; };
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int64_t n, int skip_zeros,
                                                 MinMaxPartial *__restrict__ part)
 {
-    float mn = INFINITY, mx = -INFINITY;
+    float mn = INFINITY, mx = -INFINITY, mn_nz = INFINITY, mx_nz = -INFINITY;
     unsigned long long cnt = 0;
     unsigned neg = 0, zer = 0; // per thread: well below 2^32
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
     int64_t done = 0;
-#define MM1(v) do { float v_ = (v); neg += (v_ < 0.0f); zer += (v_ == 0.0f); bool use_ = !(skip_zeros && v_ == 0.0f); if (use_) { mn = fminf(mn, v_); mx = fmaxf(mx, v_); cnt++; } } while (0)
+#define MM1(v) do { float v_ = (v); neg += (v_ < 0.0f); const bool z_ = (v_ == 0.0f); zer += z_; if (!z_) { mn_nz = fminf(mn_nz, v_); mx_nz = fmaxf(mx_nz, v_); } \
+        bool use_ = !(skip_zeros && z_); if (use_) { mn = fminf(mn, v_); mx = fmaxf(mx, v_); cnt++; } } while (0)
     if (VEC) {
         const int64_t nvec = n >> 2;
         const float4 *x4 = reinterpret_cast<const float4 *>(x);
@@ -457,16 +458,21 @@ __global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_down(mn, off));
         mx = fmaxf(mx, __shfl_down(mx, off));
+        mn_nz = fminf(mn_nz, __shfl_down(mn_nz, off));
+        mx_nz = fmaxf(mx_nz, __shfl_down(mx_nz, off));
         cnt += __shfl_down(cnt, off);
         negl += __shfl_down(negl, off);
         zerl += __shfl_down(zerl, off);
     }
     __shared__ MinMaxPartial sh[4];
-    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = negl; q.zer = zerl; sh[threadIdx.x >> 6] = q; }
+    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = negl; q.zer = zerl; q.mn_nz = mn_nz; q.mx_nz = mx_nz; sh[threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
         MinMaxPartial p = sh[0];
-        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer; }
+        for (int w = 1; w < 4; w++) {
+            p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer;
+            p.mn_nz = fminf(p.mn_nz, sh[w].mn_nz); p.mx_nz = fmaxf(p.mx_nz, sh[w].mx_nz);
+        }
         part[blockIdx.x] = p;
     }
 }
@@ -475,27 +481,33 @@ __global__ __launch_bounds__(256) void k_minmax_final(const MinMaxPartial *__res
                                                       float *__restrict__ out, long long *__restrict__ count,
                                                       long long *__restrict__ signs)
 {
-    float mn = INFINITY, mx = -INFINITY;
+    float mn = INFINITY, mx = -INFINITY, mn_nz = INFINITY, mx_nz = -INFINITY;
     unsigned long long cnt = 0, neg = 0, zer = 0;
     for (int i = threadIdx.x; i < nparts; i += 256) {
         mn = fminf(mn, part[i].mn); mx = fmaxf(mx, part[i].mx); cnt += part[i].cnt; neg += part[i].neg; zer += part[i].zer;
+        mn_nz = fminf(mn_nz, part[i].mn_nz); mx_nz = fmaxf(mx_nz, part[i].mx_nz);
     }
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_down(mn, off));
         mx = fmaxf(mx, __shfl_down(mx, off));
+        mn_nz = fminf(mn_nz, __shfl_down(mn_nz, off));
+        mx_nz = fmaxf(mx_nz, __shfl_down(mx_nz, off));
         cnt += __shfl_down(cnt, off);
         neg += __shfl_down(neg, off);
         zer += __shfl_down(zer, off);
     }
     __shared__ MinMaxPartial sh[4];
-    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = neg; q.zer = zer; sh[threadIdx.x >> 6] = q; }
+    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = neg; q.zer = zer; q.mn_nz = mn_nz; q.mx_nz = mx_nz; sh[threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
         MinMaxPartial p = sh[0];
-        for (int w = 1; w < 4; w++) { p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer; }
+        for (int w = 1; w < 4; w++) {
+            p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer;
+            p.mn_nz = fminf(p.mn_nz, sh[w].mn_nz); p.mx_nz = fmaxf(p.mx_nz, sh[w].mx_nz);
+        }
         out[0] = p.mn; out[1] = p.mx;
         if (count) *count = (long long)p.cnt;
-        if (signs) { signs[0] = (long long)p.neg; signs[1] = (long long)p.zer; }
+        if (signs) { signs[0] = (long long)p.neg; signs[1] = (long long)p.zer; out[2] = p.mn_nz; out[3] = p.mx_nz; }
     }
 }
 

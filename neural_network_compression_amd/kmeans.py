@@ -68,12 +68,58 @@ def _allreduce_(t: torch.Tensor, op, group):
     return t
 
 
+class LayerStats:
+    """NumPy-exact mean / variance, min / max (over all weights and over the non-zero ones) and the counts of
+    negative and zero weights of one vector (this rank's shard for the counts), fetched with ONE host
+    synchronisation.  What the k-means set-up, the sort and the weight distribution need."""
+
+    def __init__(self, x: torch.Tensor, n_total: int | None = None, group=None):
+        n = x.numel()
+        dev = x.device
+        n_total = n if n_total is None else n_total
+        mean_d, var_d, _ = ops.moments(x, n_total, group)
+        if n > 0:
+            mm, signs = ops.minmax_signs(x)
+        else:
+            mm = torch.tensor([np.inf, -np.inf, np.inf, -np.inf], dtype=torch.float32, device=dev)
+            signs = torch.zeros(2, dtype=torch.int64, device=dev)
+        if group is not None:
+            from . import sharding
+
+            mm = torch.cat([sharding.allreduce_minmax(mm[:2].contiguous(), group), sharding.allreduce_minmax(mm[2:].contiguous(), group)])
+        pin_f = torch.empty(6, dtype=torch.float32, pin_memory=True)
+        pin_i = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        pin_f.copy_(torch.cat([mean_d, var_d, mm]), non_blocking=True)
+        pin_i.copy_(signs, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        self.mean, self.var, self.min, self.max, self.min_nonzero, self.max_nonzero = (np.float32(v) for v in pin_f.numpy())
+        self.n_negative, self.n_zero = (int(v) for v in pin_i.numpy())
+        self.n = n
+
+
+def sorted_copy(x: torch.Tensor, stats: LayerStats) -> torch.Tensor:
+    """Ascending copy of x (nnc_sort_f32; on a pruned vector only the non-zeros are sorted)."""
+    L = nat.load()
+    stream = ops._stream(x)
+    out = torch.empty_like(x)
+    if 4 * stats.n_zero >= x.numel():
+        ws_bytes = L.nnc_sort_pruned_workspace_bytes(x.numel(), stats.n_negative, stats.n_zero)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        nat.check(L.nnc_sort_pruned_f32(x.data_ptr(), x.numel(), stats.n_negative, stats.n_zero, out.data_ptr(),
+                                        ws.data_ptr(), ws_bytes, stream))
+        return out
+    ws_bytes = L.nnc_sort_workspace_bytes(x.numel())
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    nat.check(L.nnc_sort_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws_bytes, stream))
+    return out
+
+
 class DeviceKMeans:
     """One fit = one instance.  ``x`` float32, 1-D, contiguous, CUDA."""
 
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
                  batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
-                 reloc: str = "auto"):
+                 reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -99,24 +145,12 @@ class DeviceKMeans:
             raise ValueError(f"n_samples={n_total} should be >= n_clusters={self.k}.")
         self.n, self.n_total = n, n_total
 
-        # ---- NumPy-exact mean / var, min / max  (one host sync for the whole fit set-up)
-        mean_d, var_d, _ = ops.moments(x, n_total, group)
-        if n > 0:
-            mm, signs = ops.minmax_signs(x)   # this rank's own counts of negative / zero weights: for the sort below
-        else:
-            mm = torch.tensor([np.inf, -np.inf], dtype=torch.float32, device=self.dev)
-            signs = torch.zeros(2, dtype=torch.int64, device=self.dev)
-        if group is not None:
-            from . import sharding
-
-            mm = sharding.allreduce_minmax(mm, group)
-        pin_f = torch.empty(4, dtype=torch.float32, pin_memory=True)
-        pin_i = torch.empty(2, dtype=torch.int64, pin_memory=True)
-        pin_f.copy_(torch.cat([mean_d, var_d, mm]), non_blocking=True)
-        pin_i.copy_(signs, non_blocking=True)
-        torch.cuda.current_stream(self.dev).synchronize()
-        mean, var, xmin, xmax = (np.float32(v) for v in pin_f.numpy())
-        self.n_negative, self.n_zero = (int(v) for v in pin_i.numpy())
+        # ---- NumPy-exact mean / var, min / max  (one host sync for the whole fit set-up; the caller may have them already)
+        if stats is None:
+            stats = LayerStats(x, n_total, group)
+        self.stats = stats
+        mean, var, xmin, xmax = stats.mean, stats.var, stats.min, stats.max
+        self.n_negative, self.n_zero = stats.n_negative, stats.n_zero
         self.x_mean = mean
         self.tol_ = np.float32(var * np.float32(tol))  # np.mean(np.var(X, axis=0)) * tol, float32
         lo, hi = np.float32(xmin - mean), np.float32(xmax - mean)  # exact range of the centred data
@@ -152,24 +186,12 @@ class DeviceKMeans:
         if sort is None:
             sort = n >= SORT_MIN_WEIGHTS
         self.sorted = bool(sort and n > 0)
-        self.x_iter = self._sorted_copy(x) if self.sorted else x
-        # params.flags bit 0 selects the DIRECT kernel form (runs flushed per wave straight to global atomics,
-        # no LDS accumulators, no closing barrier).  Measured slower end to end: it needs > 64 VGPRs (one
-        # workgroup per CU) and, on pruned tensors, thousands of waves end on the zero cluster's address.
-
-    def _sorted_copy(self, x: torch.Tensor) -> torch.Tensor:
-        out = torch.empty_like(x)
-        if 4 * self.n_zero >= x.numel():
-            # pruned tensor: partition the zeros out, sort only the rest
-            ws_bytes = self.L.nnc_sort_pruned_workspace_bytes(x.numel(), self.n_negative, self.n_zero)
-            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
-            nat.check(self.L.nnc_sort_pruned_f32(x.data_ptr(), x.numel(), self.n_negative, self.n_zero, out.data_ptr(),
-                                                 ws.data_ptr(), ws_bytes, self.stream))
-            return out
-        ws_bytes = self.L.nnc_sort_workspace_bytes(x.numel())
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
-        nat.check(self.L.nnc_sort_f32(x.data_ptr(), x.numel(), out.data_ptr(), ws.data_ptr(), ws_bytes, self.stream))
-        return out
+        if x_sorted is not None:
+            if x_sorted.numel() != n or x_sorted.dtype != torch.float32 or not x_sorted.is_cuda:
+                raise ValueError("x_sorted must be a float32 CUDA vector as long as x")
+            self.sorted, self.x_iter = True, x_sorted
+        else:
+            self.x_iter = sorted_copy(x, stats) if self.sorted else x
 
     # -------------------------------------------------------------- low-level steps
     def status(self) -> nat.KMeansStatus:

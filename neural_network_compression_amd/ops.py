@@ -143,12 +143,13 @@ def minmax(x: torch.Tensor, skip_zeros: bool = False):
 
 
 def minmax_signs(x: torch.Tensor):
-    """(float32[2] = {min, max}, int64[2] = {#negative, #zero}) on the device, one pass."""
+    """(float32[4] = {min, max, min over the non-zeros, max over the non-zeros}, int64[2] = {#negative, #zero})
+    on the device, one pass."""
     _require_cuda(x, "x", torch.float32)
     if x.numel() == 0:
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     L = nat.load()
-    out = torch.empty(2, dtype=torch.float32, device=x.device)
+    out = torch.empty(4, dtype=torch.float32, device=x.device)
     signs = torch.empty(2, dtype=torch.int64, device=x.device)
     ws_bytes = L.nnc_minmax_workspace_bytes(x.numel())
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)

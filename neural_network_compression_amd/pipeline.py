@@ -63,6 +63,25 @@ def weight_distribution(x: torch.Tensor, skip_zeros: bool = True, group=None):
     return utility._cdf_from_counts(steps, counts)
 
 
+def weight_distribution_sorted(x_sorted: torch.Tensor, stats):
+    """get_weight_distribution of the non-zero weights (utility.py:334-392, Trainer.quantize strips the zeros
+    first) from a value-sorted copy: the 31 bin counts are differences of 32 ranks (one binary search each)
+    instead of a pass over the vector.  Same float32 comparisons as the histogram kernel: bin b holds
+    steps[b] <= w < steps[b+1]."""
+    if stats.n_zero >= x_sorted.numel():
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    steps = np.linspace(np.float32(stats.min_nonzero), np.float32(stats.max_nonzero), num=32)  # float32 under NumPy 2
+    steps32 = np.ascontiguousarray(steps, dtype=np.float32)
+    steps_d = torch.from_numpy(steps32).to(x_sorted.device)
+    ranks = torch.searchsorted(x_sorted, steps_d, right=False).cpu().numpy().astype(np.int64)  # #{w < steps[b]}
+    counts = np.diff(ranks)
+    zero = np.float32(0.0)
+    inside = np.nonzero((steps32[:-1] <= zero) & (zero < steps32[1:]))[0]
+    if inside.size:
+        counts[inside[0]] -= stats.n_zero   # the zeros sit in that bin of the full vector
+    return utility._cdf_from_counts(steps, counts)
+
+
 def initial_centroids(x: torch.Tensor, bits: int, mode: str, cdfs=None, group=None, n_total=None) -> np.ndarray:
     """The reference's init `space` (utility.py:206-226) for a possibly sharded vector."""
     if group is None:
@@ -108,9 +127,19 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         return LayerResult(mask, nz, sigma, thr, x, None, None, None, None, None)
     if with_cdf is None:
         with_cdf = mode == "density"
-    cdfs = weight_distribution(x, skip_zeros=True, group=group) if with_cdf else None
-    space = initial_centroids(x, bits, mode, cdfs, group, n_total)
-    km = _kmeans.DeviceKMeans(x, space, group=group)
+    lstats = x_sorted = None
+    if group is None and x.numel() >= _kmeans.SORT_MIN_WEIGHTS:
+        # long vector on one GPU: one statistics pass and one sort serve the weight distribution, the init and the fit
+        lstats = _kmeans.LayerStats(x)
+        x_sorted = _kmeans.sorted_copy(x, lstats)
+        cdfs = weight_distribution_sorted(x_sorted, lstats) if with_cdf else None
+    else:
+        cdfs = weight_distribution(x, skip_zeros=True, group=group) if with_cdf else None
+    if mode == "linear" and lstats is not None:
+        space = np.linspace(np.float32(lstats.min), np.float32(lstats.max), num=2 ** bits).astype(np.float32)
+    else:
+        space = initial_centroids(x, bits, mode, cdfs, group, n_total)
+    km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted)
     model, values = km.fit(want_values=want_values)
     counts = lengths = lhist = total = None
     if huffman:

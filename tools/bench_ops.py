@@ -48,7 +48,7 @@ timeit("apply_mask_", lambda: ops.apply_mask_(x, mask), bytes_=5 * n)
 init = np.linspace(-0.25, 0.25, 256).astype(np.float32)
 km = kmeans.DeviceKMeans(x, init)
 timeit("DeviceKMeans.__init__ (moments+sort)", lambda: kmeans.DeviceKMeans(x, init), reps=3)
-timeit("sorted copy", lambda: km._sorted_copy(x), bytes_=4 * n)
+timeit("sorted copy", lambda: kmeans.sorted_copy(x, km.stats), bytes_=4 * n)
 timeit("assign labels+values", lambda: km.assign(0, True, True, False), bytes_=9 * n)
 timeit("assign labels+dist", lambda: km.assign(0, True, False, True), bytes_=9 * n)
 lab, _, d = km.assign(0, True, False, True)
