@@ -197,6 +197,14 @@ int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, void *stream)
  * the host polls that word until it reads its ticket, then reads the status. */
 int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t ticket, void *stream);
 int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream);
+/* counts_dev[j] (int64, k entries) = number of weights of x whose nearest centre is j, for the
+ * current centres (which = 0) or the previous ones (which = 1): the index histogram the Huffman
+ * step needs, from one more streaming pass over any permutation of the vector (e.g. the sorted
+ * copy) instead of a count over the label vector.  Call between iterations or after the fit; it
+ * ignores done / paused and leaves the state as it was. */
+int nnc_kmeans_label_counts(const float *x, void *ws, const nnc_kmeans_params *p, int which, int64_t *counts_dev,
+                            void *stream);
+
 /* which: 0 = current centres (used by the next E-step), 1 = centres of the previous E-step.
  * centred != 0: as stored (x_mean subtracted); else un-centred (+ x_mean, float32 add). */
 int nnc_kmeans_get_centers(void *ws, int which, int centred, float *out_dev, void *stream);

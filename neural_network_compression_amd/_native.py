@@ -77,6 +77,7 @@ SIGNATURES = {
     "nnc_kmeans_status_async": (c_int, [c_void_p, ctypes.POINTER(KMeansStatus), c_void_p]),
     "nnc_kmeans_status_publish": (c_int, [c_void_p, c_void_p, ctypes.c_uint64, c_void_p]),
     "nnc_kmeans_set_done": (c_int, [c_void_p, c_i32, c_void_p]),
+    "nnc_kmeans_label_counts": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_int, c_void_p, c_void_p]),
     "nnc_kmeans_get_centers": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_assign": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nnc_topm_hist_f32": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_i32, ctypes.c_uint32, c_void_p, c_void_p]),

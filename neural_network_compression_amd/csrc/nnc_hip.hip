@@ -1055,13 +1055,13 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
 #pragma unroll
     for (int j = 0; j < KM_RING; j++) r[j] = ld(s0 + j);
 
-    if (MODE == 0 && (ws->st.done | ws->st.paused)) return;
+    if (MODE == 0 && !(which & 2) && (ws->st.done | ws->st.paused)) return; // (which & 2: counting pass after the fit, see nnc_kmeans_label_counts)
     if (MODE == 1 && n_dev && s0 >= s1 && blockIdx.x != gridDim.x - 1) return; // nothing in this workgroup's range
     const int k = ws->p.k;
     const int glog2 = ws->glog2, rlog2 = ws->rlog2;
     const int G = 1 << glog2;
     const int kp = (k + 7) & ~7;
-    const int t = ws->cur ^ (MODE == 1 ? (which & 1) : 0);
+    const int t = ws->cur ^ (which & 1);
     const KmTab *__restrict__ tab = &ws->tab[t];
     const int kt = tab->ku; // distinct centres: the sorted tables hold only those
 
@@ -1814,7 +1814,7 @@ extern "C" int nnc_debug_clock(int blocks, int iters, float *out_dev, void *stre
 static int g_ablation = 0;
 extern "C" int nnc_debug_set_ablation(int a) { g_ablation = a; return NNC_OK; }
 
-static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream)
+static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream, int which = 0)
 {
     int glog2, rlog2;
     km_defaults(p, &glog2, &rlog2);
@@ -1828,7 +1828,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     // command processor's arrival), so the difference is the launch's execution time
     hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
     hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
-#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, 0, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr)
+#define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, which, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr)
     const bool direct = (p->flags & 1) != 0; // caller promises long runs of equal cluster index (value-sorted input)
     if (vec && direct && g_ablation == 0) KM_LAUNCH_ACC(true, uint8_t, 0, true);
     else if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
@@ -1900,6 +1900,40 @@ extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_par
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
         if ((rc = km_launch_finalize(w, FIN_FROM_SHARDS, 0, stream))) return rc;
     }
+    return NNC_OK;
+}
+
+// index histogram of the E-step on the current (which = 0) or previous (which = 1) centres, from the per-cluster
+// counts of one more streaming pass (any order of the weights gives the same counts, so the value-sorted copy may
+// be used: far cheaper than counting the labels of the original vector)
+__global__ __launch_bounds__(KM_THREADS) void k_counts_from_shards(KmWs *__restrict__ ws, int which, long long *__restrict__ counts)
+{
+    const KmTab *tab = &ws->tab[ws->cur ^ (which & 1)];
+    const int k = ws->p.k, ku = tab->ku;
+    for (int j = threadIdx.x; j < k; j += KM_THREADS) counts[j] = 0; // duplicates of a centre own nothing
+    __syncthreads();
+    for (int p = threadIdx.x; p < ku; p += KM_THREADS) {
+        unsigned long long c = 0;
+        for (int sh = 0; sh < KM_NSHARD; sh++) {
+            c += ws->shard_cnt[sh][p];
+            ws->shard_sum[sh][p] = 0; ws->shard_cnt[sh][p] = 0;
+        }
+        counts[tab->orig[p]] = (long long)c;
+    }
+}
+
+extern "C" int nnc_kmeans_label_counts(const float *x, void *ws, const nnc_kmeans_params *pp, int which, int64_t *counts_dev,
+                                       void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_label_counts");
+    if (rc) return rc;
+    if (!counts_dev || (pp->n > 0 && !x)) return fail(NNC_EINVAL, "nnc_kmeans_label_counts: null pointer");
+    if ((rc = km_set_lds_attr())) return rc;
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    const nnc_kmeans_params p = *pp;
+    if ((rc = km_launch_accumulate(x, w, &p, stream, 2 | (which & 1)))) return rc;
+    hipLaunchKernelGGL(k_counts_from_shards, dim3(1), dim3(KM_THREADS), 0, S(stream), w, which, reinterpret_cast<long long *>(counts_dev));
+    LAUNCHCHK("k_counts_from_shards");
     return NNC_OK;
 }
 
@@ -2130,7 +2164,18 @@ __device__ void km_relocate_body(KmWs *__restrict__ ws, const long long *__restr
         const float xc = xv - mean;
         float best = cen[0] * cen[0] + (-2.0f * (xc * cen[0]));
         int old = 0;
-        for (int j = 1; j < k; j++) {
+        int j = 1;
+        for (; j + 8 <= k; j += 8) { // eight LDS reads in flight
+            float cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cv[u] = cen[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float dj = cv[u] * cv[u] + (-2.0f * (xc * cv[u]));
+                if (dj < best) { best = dj; old = j + u; }
+            }
+        }
+        for (; j < k; j++) {
             const float dj = cen[j] * cen[j] + (-2.0f * (xc * cen[j]));
             if (dj < best) { best = dj; old = j; }
         }
@@ -2298,6 +2343,9 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     __shared__ KmRelocLds rl;
     __shared__ double zl_s[NNC_KMAX];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long *strc = g_km_trace; // diagnostics: phase stamps behind the workgroup records
+#define RSTAMP(i) do { if (strc && tid == 0) strc[3000 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    RSTAMP(0);
     const int n_cand = meta[0];
     {
         int bad0 = meta[2] ? 1 : 0;
@@ -2379,6 +2427,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         __syncthreads();
         if (total_ge <= KM_SURV_SMALL) break;
     }
+    RSTAMP(1);
+    if (strc && tid == 0) { strc[3010] = (unsigned long long)n_cand; strc[3011] = (unsigned long long)total_ge; }
     int bad = 0;
     if (total_ge > KM_SURV_MAX) bad |= 128; // a crowd of exactly equal distances at the cut
     if (tid == 0) { s_nsurv = 0; s_bad = 0; }
@@ -2407,20 +2457,29 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         for (int i = (nvec << 2) + tid; i < n_cand; i += KM_THREADS) take(__float_as_uint(cand_d[i]), i);
     }
     __syncthreads();
+    RSTAMP(2);
     const int m = min(s_nsurv, KM_SURV_MAX);
     if (!bad && m < n_empty) bad |= 2;
     if (!bad) {
         if (m <= KM_SURV_SMALL) {
-            // few survivors: rank by counting (ties cannot matter: equal keys are interchangeable)
+            // few survivors: rank by counting; the m * m comparisons are spread over all threads (P of them share
+            // a survivor, each takes a slice of the others; 64-bit compares are slow, so the VALU time matters)
+            int *rank_s = reinterpret_cast<int *>(hist); // the histogram is done with
+            const int P = max(1, KM_THREADS / max(m, 1));
+            const int slice = (m + P - 1) / P;
+            for (int i = tid; i < m; i += KM_THREADS) rank_s[i] = 0;
+            __syncthreads();
             unsigned long long mine = 0ull;
-            int r = -1;
-            if (tid < m) {
-                mine = surv[tid];
-                r = 0;
-                for (int j = 0; j < m; j++) { const unsigned long long kj = surv[j]; r += (kj > mine) || (kj == mine && j < tid); }
+            const int i = tid % max(m, 1), part = tid / max(m, 1);
+            if (part < P && m > 0) {
+                mine = surv[i];
+                int r = 0;
+                const int j1 = min(m, (part + 1) * slice);
+                for (int j = part * slice; j < j1; j++) { const unsigned long long kj = surv[j]; r += (kj > mine) || (kj == mine && j < i); }
+                if (r) atomicAdd(&rank_s[i], r);
             }
             __syncthreads();
-            if (r >= 0) surv[r] = mine;
+            if (part == 0 && m > 0) surv[rank_s[i]] = mine; // every rank 0 .. m-1 is taken exactly once
         } else {
             // bitonic sort, descending, of the survivors (padded with zeros to a power of two)
             int M = 2;
@@ -2440,6 +2499,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         for (int r = tid; r < n_empty; r += KM_THREADS) keys_out[r] = (long long)surv[r];
     }
     __syncthreads();
+    RSTAMP(3);
     if (!bad) {
         const unsigned dT = (unsigned)(surv[n_empty - 1] >> 32);
         const KmTab *tab = &ws->tab[ws->cur];
@@ -2449,6 +2509,22 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         double *zr_s = reinterpret_cast<double *>(hist); // 4096 * 4 B = 2048 doubles
         for (int q = tid; q < ku; q += KM_THREADS) { zr_s[q] = tab->zr[q]; zl_s[q] = tab->zl[q]; }
         __syncthreads();
+        // running maximum of the upper ends (from below) and running minimum of the lower ends (from above):
+        // Hillis-Steele over at most NNC_KMAX values, two per thread
+        for (int off = 1; off < ku; off <<= 1) {
+            double a[2], b[2];
+            for (int r = 0; r < 2; r++) {
+                const int q = tid + r * KM_THREADS;
+                a[r] = (q < ku && q >= off) ? fmax(zr_s[q], zr_s[q - off]) : (q < ku ? zr_s[q] : 0.0);
+                b[r] = (q < ku && q + off < ku) ? fmin(zl_s[q], zl_s[q + off]) : (q < ku ? zl_s[q] : 0.0);
+            }
+            __syncthreads();
+            for (int r = 0; r < 2; r++) {
+                const int q = tid + r * KM_THREADS;
+                if (q < ku) { zr_s[q] = a[r]; zl_s[q] = b[r]; }
+            }
+            __syncthreads();
+        }
         for (int j = tid; j + 1 < nwin; j += KM_THREADS) {
             const KmWin a = win[j], b = win[j + 1];
             if (b.start > a.start + a.len) { // samples between the two windows that are no candidates
@@ -2461,8 +2537,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
                 // every value in [u, w] must have centre j (value order) as its only candidate:
                 // above the zones of all smaller centres, below the zones of all larger ones
                 const double uc = (double)(u - mean), wc = (double)(w - mean);
-                for (int q = 0; q < j && q < ku; q++) if (!(uc > zr_s[q])) bad |= 8;
-                for (int q = j + 1; q < ku; q++) if (!(wc < zl_s[q])) bad |= 16;
+                if (j > 0 && j - 1 < ku && !(uc > zr_s[j - 1])) bad |= 8;
+                if (j + 1 < ku && !(wc < zl_s[j + 1])) bad |= 16;
                 if (!(du < dT)) bad |= 32;
                 if (!(dw < dT)) bad |= 64;
             }
@@ -2472,11 +2548,14 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     // stretch inside another centre's zone, 32 / 64 lower / upper end not strictly below the cut, 128 tie crowd
     if (bad) atomicOr(&s_bad, bad);
     __syncthreads();
+    RSTAMP(4);
     const int any_bad = s_bad;
     if (tid == 0) ws->reloc_fail = any_bad;
     if (any_bad) return;
     __threadfence_block();
     km_relocate_body(ws, keys_out, n_empty, &rl);
+    RSTAMP(5);
+#undef RSTAMP
 }
 
 extern "C" int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window,

@@ -46,6 +46,7 @@ class QuantizedModel:
         self.n_relocations_ = int(n_relocations)
         self.stop_reason_ = stop
         self._labels_np = None
+        self.counts_device_ = None   # int64[K] index histogram of labels_ (this rank's shard), device
 
     def labels_device(self) -> torch.Tensor:
         """int32 centroid indices on the device."""
@@ -407,4 +408,9 @@ class DeviceKMeans:
         else:
             lab, vals, _ = self.assign(which=0, labels=True, values=want_values)
         model = QuantizedModel(centers, lab, st.iter, self.n_relocations, stop)
+        # index histogram of these labels (this rank's shard), from one more pass over the iteration copy
+        counts = torch.empty(self.k, dtype=torch.int64, device=self.dev)
+        nat.check(self.L.nnc_kmeans_label_counts(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
+                                                 1 if strict_labels is not None else 0, counts.data_ptr(), self.stream))
+        model.counts_device_ = counts
         return model, vals

@@ -143,7 +143,9 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
     model, values = km.fit(want_values=want_values)
     counts = lengths = lhist = total = None
     if huffman:
-        counts_d = ops.bincount(model.labels_compact_, km.k)
+        counts_d = getattr(model, "counts_device_", None)
+        if counts_d is None:
+            counts_d = ops.bincount(model.labels_compact_, km.k)
         if group is not None:
             sharding.allreduce_sum_(counts_d, group)
         counts = counts_d.cpu().numpy()

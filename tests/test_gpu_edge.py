@@ -28,6 +28,7 @@ def _check(kmeans, x, init, **kw):
     assert np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
     assert np.array_equal(model.labels_, ob.labels_), int((model.labels_ != ob.labels_).sum())
     assert np.array_equal(vals.cpu().numpy(), ob.cluster_centers_.ravel()[ob.labels_])
+    assert np.array_equal(model.counts_device_.cpu().numpy(), np.bincount(ob.labels_, minlength=len(init)))
     return model
 
 
@@ -115,6 +116,7 @@ def _fit_pair(kmeans, x, init):
         assert model.n_iter_ == ob.n_iter_, (mode, model.n_iter_, ob.n_iter_)
         assert np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), mode
         assert np.array_equal(model.labels_, ob.labels_), mode
+        assert np.array_equal(model.counts_device_.cpu().numpy(), np.bincount(ob.labels_, minlength=len(init))), mode
         kms[mode] = km
     assert kms["full"].n_reloc_windowed == 0
     assert kms["auto"].n_relocations == kms["full"].n_relocations
