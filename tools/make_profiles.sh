@@ -33,7 +33,7 @@ for name, v in fetch.items():
     if name.startswith("void k_") or name.startswith("k_"):
         v = sorted(v)
         # keep launches that did real work (iterations enqueued after convergence return at once)
-        live = [x for x in v if x > 0.3 * v[len(v) // 2]] or v
+        live = [x for x in v if x > 0.6 * v[len(v) // 2]] or v
         summ[name[:60]] = {"launches": len(live), "FETCH_SIZE_KB_mean": sum(live) / len(live)}
 for name, v in write.items():
     if name[:60] in summ:
