@@ -270,6 +270,17 @@ int32_t nnc_kmeans_reloc_window(int64_t n, int32_t n_empty);
 size_t nnc_kmeans_reloc_scratch_bytes(int32_t k, int32_t window);
 int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
                                  void *scratch_dev, size_t scratch_bytes, void *stream);
+/* The same for a sharded vector (one rank per GPU): nnc_kmeans_reloc_select_local leaves this
+ * rank's n_empty farthest keys (descending) in keys_out_dev and its verdict (0 = proven) in the
+ * int32 nnc_kmeans_reloc_flag(ws) points to, without touching the sums.  The caller all-gathers the
+ * keys, all-reduces (MAX) the verdict word in place, sorts the gathered keys and hands the first
+ * n_empty to nnc_kmeans_relocate_if_proven, which edits the (already all-reduced) sums on every
+ * rank alike -- or does nothing if any verdict was non-zero; nnc_kmeans_finalize(resume = 1)
+ * then reports paused = 2 on every rank. */
+int nnc_kmeans_reloc_select_local(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
+                                  void *scratch_dev, size_t scratch_bytes, int64_t *keys_out_dev, void *stream);
+int32_t *nnc_kmeans_reloc_flag(void *ws);
+int nnc_kmeans_relocate_if_proven(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream);
 /* diagnostics: why the last proof failed (0 = it held); synchronous */
 int nnc_debug_reloc_fail(void *ws, int32_t *host_out);
 /* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence

@@ -88,6 +88,9 @@ SIGNATURES = {
     "nnc_kmeans_reloc_window": (c_i32, [c_i64, c_i32]),
     "nnc_kmeans_reloc_scratch_bytes": (c_size, [c_i32, c_i32]),
     "nnc_kmeans_relocate_windowed": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p]),
+    "nnc_kmeans_reloc_select_local": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p, c_void_p]),
+    "nnc_kmeans_reloc_flag": (c_void_p, [c_void_p]),
+    "nnc_kmeans_relocate_if_proven": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),

@@ -2334,7 +2334,8 @@ __global__ __launch_bounds__(256) void k_reloc_fill(const float *__restrict__ xs
 // the windows can beat them, and -- if it holds -- the relocation itself.
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
                                                              const float *__restrict__ cand_d, const KmWin *__restrict__ win,
-                                                             const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out)
+                                                             const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out,
+                                                             int do_relocate)
 {
     __shared__ __align__(8) unsigned hist[4096];
     __shared__ unsigned long long surv[KM_SURV_MAX];
@@ -2551,7 +2552,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     RSTAMP(4);
     const int any_bad = s_bad;
     if (tid == 0) ws->reloc_fail = any_bad;
-    if (any_bad) return;
+    if (any_bad || !do_relocate) return; // (sharded vector: the ranks first exchange their keys and their verdicts)
     __threadfence_block();
     km_relocate_body(ws, keys_out, n_empty, &rl);
     RSTAMP(5);
@@ -2590,7 +2591,7 @@ extern "C" int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, co
         return fail(NNC_EINVAL, "nnc_kmeans_relocate_checked: bad argument");
     hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x_dev, cand_d_dev,
                        reinterpret_cast<const KmWin *>(win_dev), reinterpret_cast<const int *>(meta_dev), (int)n_empty,
-                       reinterpret_cast<long long *>(keys_out_dev));
+                       reinterpret_cast<long long *>(keys_out_dev), 1);
     LAUNCHCHK("k_reloc_select");
     return NNC_OK;
 }
@@ -2640,6 +2641,60 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
     if ((rc = km_assign(cand_x, ws, &pc, 0, nullptr, 1, nullptr, cand_d, nullptr, meta, stream))) return rc; // meta[0] = n_cand
     if ((rc = nnc_kmeans_relocate_checked(ws, cand_x, cand_d, win, meta, n_empty, keys, stream))) return rc;
     return nnc_kmeans_finalize(ws, 1, stream);
+}
+
+// Sharded vector: every rank selects (and proves) its own n_empty farthest samples from its shard's windows; the ranks
+// then all-gather the keys and all-reduce (MAX) the verdict word nnc_kmeans_reloc_flag(); the merged top n_empty go to
+// nnc_kmeans_relocate_if_proven, which does nothing if any rank's proof failed (the resumed finalize then reports
+// paused = 2 on every rank and the full-pass form takes over).
+extern "C" int nnc_kmeans_reloc_select_local(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
+                                             void *scratch_dev, size_t scratch_bytes, int64_t *keys_out_dev, void *stream)
+{
+    int rc = km_check(ws, p, "nnc_kmeans_reloc_select_local");
+    if (rc) return rc;
+    const int32_t window = nnc_kmeans_reloc_window(p->n, n_empty);
+    if (window == 0) return fail(NNC_EINVAL, "nnc_kmeans_reloc_select_local: not applicable (nnc_kmeans_reloc_window() == 0)");
+    if (!x_sorted || !scratch_dev || !keys_out_dev || (reinterpret_cast<uintptr_t>(scratch_dev) & 255) != 0)
+        return fail(NNC_EINVAL, "nnc_kmeans_reloc_select_local: null or unaligned (256 B) pointer");
+    if (scratch_bytes < nnc_kmeans_reloc_scratch_bytes(p->k, window)) return fail(NNC_ENOSPACE, "nnc_kmeans_reloc_select_local: scratch too small");
+    const int64_t cap = reloc_cap(p->k, window);
+    unsigned char *b = reinterpret_cast<unsigned char *>(scratch_dev);
+    float *cand_x = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
+    float *cand_d = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
+    void *win = b; b += reloc_align(16 * (size_t)(p->k + 2));
+    int32_t *meta = reinterpret_cast<int32_t *>(b);
+    if ((rc = nnc_kmeans_reloc_candidates(x_sorted, ws, p, window, cand_x, cap, win, meta, stream))) return rc;
+    nnc_kmeans_params pc = *p;
+    pc.n = cap;
+    pc.n_total = std::max<int64_t>(cap, p->n_total);
+    if ((rc = km_assign(cand_x, ws, &pc, 0, nullptr, 1, nullptr, cand_d, nullptr, meta, stream))) return rc; // meta[0] = n_cand
+    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
+                       reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
+                       reinterpret_cast<long long *>(keys_out_dev), 0);
+    LAUNCHCHK("k_reloc_select");
+    return NNC_OK;
+}
+
+extern "C" int32_t *nnc_kmeans_reloc_flag(void *ws)
+{
+    if (!ws) return nullptr;
+    return &reinterpret_cast<KmWs *>(ws)->reloc_fail;
+}
+
+__global__ __launch_bounds__(KM_THREADS) void k_relocate_if_proven(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys)
+{
+    __shared__ KmRelocLds lds;
+    if (ws->reloc_fail) return;
+    km_relocate_body(ws, keys, nkeys, &lds);
+}
+
+extern "C" int nnc_kmeans_relocate_if_proven(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream)
+{
+    if (!ws || !keys_sorted_dev || nkeys < 1) return fail(NNC_EINVAL, "nnc_kmeans_relocate_if_proven: bad argument");
+    hipLaunchKernelGGL(k_relocate_if_proven, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws),
+                       reinterpret_cast<const long long *>(keys_sorted_dev), nkeys);
+    LAUNCHCHK("k_relocate_if_proven");
+    return NNC_OK;
 }
 
 // flag = 1 if the two label vectors are identical, else 0

@@ -136,12 +136,16 @@ class DeviceKMeans:
             raise ValueError(f"number of centroids {self.k} out of range")
         n = x.numel()
         n_total = n
+        self.n_min = n
         if group is not None:
             import torch.distributed as dist
 
-            t = torch.tensor([n], dtype=torch.int64, device=self.dev)
+            t = torch.tensor([n, -n], dtype=torch.int64, device=self.dev)
+            tm = t.clone()
             _allreduce_(t, dist.ReduceOp.SUM, group)
-            n_total = int(t.item())
+            _allreduce_(tm, dist.ReduceOp.MAX, group)
+            n_total = int(t[0].item())
+            self.n_min = -int(tm[1].item())   # the smallest shard: decisions every rank must take alike depend on it
         if n_total < self.k:
             raise ValueError(f"n_samples={n_total} should be >= n_clusters={self.k}.")
         self.n, self.n_total = n, n_total
@@ -169,6 +173,9 @@ class DeviceKMeans:
         # view of the device partials (2K int64) inside the workspace, for the all-reduce / relocation edits
         off = pptr - self.ws.data_ptr()
         self.partials = self.ws[off: off + 16 * self.k].view(torch.int64)
+        # view of the relocation verdict word inside the workspace (all-reduced across ranks in the sharded form)
+        foff = self.L.nnc_kmeans_reloc_flag(self.ws.data_ptr()) - self.ws.data_ptr()
+        self._reloc_flag = self.ws[foff: foff + 4].view(torch.int32)
         self.n_relocations = 0
         self.n_reloc_windowed = 0   # relocation events settled by the windowed selection
         self.n_reloc_full = 0       # ... by the full distance pass
@@ -185,12 +192,14 @@ class DeviceKMeans:
         # The iterations stream a value-sorted copy (same sums in any order, far fewer LDS atomics);
         # labels, values and relocation distances always come from the original vector.
         if sort is None:
-            sort = n >= SORT_MIN_WEIGHTS
+            sort = self.n_min >= SORT_MIN_WEIGHTS
         self.sorted = bool(sort and n > 0)
+        self.sorted_everywhere = bool(sort and self.n_min > 0)
         if x_sorted is not None:
             if x_sorted.numel() != n or x_sorted.dtype != torch.float32 or not x_sorted.is_cuda:
                 raise ValueError("x_sorted must be a float32 CUDA vector as long as x")
             self.sorted, self.x_iter = True, x_sorted
+            self.sorted_everywhere = group is None
         else:
             self.x_iter = sorted_copy(x, stats) if self.sorted else x
 
@@ -297,15 +306,31 @@ class DeviceKMeans:
         """The same relocation from windows of candidates around the cluster boundaries of the
         value-sorted vector (include/nnc.h, nnc_kmeans_relocate_windowed): no pass over the
         vector, no host read.  The device proves the selection; if it cannot, the resumed finalize
-        leaves status.paused = 2 and the caller comes back through the full pass."""
-        window = int(self.L.nnc_kmeans_reloc_window(self.n, n_empty))
+        leaves status.paused = 2 and the caller comes back through the full pass.
+        Sharded: every rank selects from its own shard, the ranks exchange keys and verdicts."""
+        window = int(self.L.nnc_kmeans_reloc_window(self.n_min, n_empty))   # the same decision on every rank
         if window == 0:
             return False
         need = int(self.L.nnc_kmeans_reloc_scratch_bytes(self.k, window))
         if self._reloc_scratch is None or self._reloc_scratch.numel() < need:
             self._reloc_scratch = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        nat.check(self.L.nnc_kmeans_relocate_windowed(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), n_empty,
-                                                      self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(), self.stream))
+        ws = self.ws.data_ptr()
+        if self.group is None:
+            nat.check(self.L.nnc_kmeans_relocate_windowed(self.x_iter.data_ptr(), ws, ctypes.byref(self.p), n_empty,
+                                                          self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(), self.stream))
+            return True
+        import torch.distributed as dist
+
+        keys = torch.empty(n_empty, dtype=torch.int64, device=self.dev)
+        nat.check(self.L.nnc_kmeans_reloc_select_local(self.x_iter.data_ptr(), ws, ctypes.byref(self.p), n_empty,
+                                                       self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(),
+                                                       keys.data_ptr(), self.stream))
+        dist.all_reduce(self._reloc_flag, op=dist.ReduceOp.MAX, group=self.group)   # any rank unproven -> nobody relocates
+        bufs = [torch.empty_like(keys) for _ in range(dist.get_world_size(self.group))]
+        dist.all_gather(bufs, keys, group=self.group)
+        merged = torch.sort(torch.cat(bufs), descending=True).values[:n_empty].contiguous()
+        nat.check(self.L.nnc_kmeans_relocate_if_proven(ws, merged.data_ptr(), n_empty, self.stream))
+        nat.check(self.L.nnc_kmeans_finalize(ws, 1, self.stream))
         return True
 
     def _relocate_and_resume(self, st) -> None:
@@ -321,7 +346,7 @@ class DeviceKMeans:
         defined (CPU-dispatch dependent) pairing otherwise."""
         n_empty = int(st.n_empty)
         strict_check = st.iter >= 1 and st.same_counts
-        if (self.reloc == "auto" and self.sorted and self.group is None and int(st.paused) == 1 and not strict_check
+        if (self.reloc == "auto" and self.sorted_everywhere and int(st.paused) == 1 and not strict_check
                 and self._relocate_windowed(n_empty)):
             self.n_relocations += 1
             self.n_reloc_windowed += 1   # provisional: a failed proof comes back as paused == 2 and is redone in full
@@ -413,4 +438,5 @@ class DeviceKMeans:
         nat.check(self.L.nnc_kmeans_label_counts(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
                                                  1 if strict_labels is not None else 0, counts.data_ptr(), self.stream))
         model.counts_device_ = counts
+        model.n_reloc_windowed_ = self.n_reloc_windowed   # relocation events settled without a pass over the vector
         return model, vals

@@ -31,7 +31,7 @@ def main():
     labels = res.model.labels_
     out = {
         "rank": rank, "lo": lo, "hi": hi, "n_iter": res.model.n_iter_, "stop": res.model.stop_reason_,
-        "relocations": res.model.n_relocations_,
+        "relocations": res.model.n_relocations_, "windowed": res.model.n_reloc_windowed_,
         "centers": hashlib.sha256(res.model.cluster_centers_.tobytes()).hexdigest(),
         "labels": hashlib.sha256(labels.astype(np.int32).tobytes()).hexdigest(),
         "values": hashlib.sha256(res.values.cpu().numpy().tobytes()).hexdigest(),

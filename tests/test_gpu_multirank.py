@@ -55,11 +55,15 @@ def _run(world, args):
 def test_sharded_fit_equals_single_process(args):
     assert torch.cuda.is_available()
     one = _run(1, args)[0]
+    if args[4] == "density":
+        assert one["relocations"] >= 1
     for world in (2, 3):
         many = _run(world, args)
         for o in many:
             assert o["n_iter"] == one["n_iter"] and o["stop"] == one["stop"], (world, o["n_iter"], one["n_iter"])
-            assert o["centers"] == one["centers"]
+            assert o["centers"] == one["centers"] and o["relocations"] == one["relocations"]
+            if args[4] == "density":
+                assert o["windowed"] >= 1   # the sharded form of the windowed relocation ran
             assert o["counts"] == one["counts"] and o["total_bits"] == one["total_bits"]
             assert o["nzeroed"] == one["nzeroed"] and o["sigma"] == one["sigma"]
             ref = one["shards"][f"{world}:{o['rank']}"]
