@@ -120,7 +120,8 @@ class DeviceKMeans:
 
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
                  batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
-                 reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None):
+                 reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
+                 n_total: int | None = None, n_min: int | None = None):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -135,9 +136,13 @@ class DeviceKMeans:
         if not (1 <= self.k <= nat.NNC_KMAX - 8):
             raise ValueError(f"number of centroids {self.k} out of range")
         n = x.numel()
-        n_total = n
-        self.n_min = n
-        if group is not None:
+        known = n_total is not None and n_min is not None   # the caller has counted the shards already
+        if known:
+            self.n_min = int(n_min)
+        else:
+            n_total = n
+            self.n_min = n
+        if group is not None and not known:
             import torch.distributed as dist
 
             t = torch.tensor([n, -n], dtype=torch.int64, device=self.dev)
@@ -199,7 +204,7 @@ class DeviceKMeans:
             if x_sorted.numel() != n or x_sorted.dtype != torch.float32 or not x_sorted.is_cuda:
                 raise ValueError("x_sorted must be a float32 CUDA vector as long as x")
             self.sorted, self.x_iter = True, x_sorted
-            self.sorted_everywhere = group is None
+            self.sorted_everywhere = True   # the caller sorts on every rank or on none
         else:
             self.x_iter = sorted_copy(x, stats) if self.sorted else x
 

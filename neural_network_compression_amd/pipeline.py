@@ -63,22 +63,26 @@ def weight_distribution(x: torch.Tensor, skip_zeros: bool = True, group=None):
     return utility._cdf_from_counts(steps, counts)
 
 
-def weight_distribution_sorted(x_sorted: torch.Tensor, stats):
+def weight_distribution_sorted(x_sorted: torch.Tensor, stats, group=None):
     """get_weight_distribution of the non-zero weights (utility.py:334-392, Trainer.quantize strips the zeros
     first) from a value-sorted copy: the 31 bin counts are differences of 32 ranks (one binary search each)
     instead of a pass over the vector.  Same float32 comparisons as the histogram kernel: bin b holds
-    steps[b] <= w < steps[b+1]."""
-    if stats.n_zero >= x_sorted.numel():
+    steps[b] <= w < steps[b+1].  Sharded: every rank ranks the steps in its own sorted shard, the ranks add up."""
+    if not np.isfinite(stats.min_nonzero):   # no non-zero weight anywhere (min over nothing = +inf)
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     steps = np.linspace(np.float32(stats.min_nonzero), np.float32(stats.max_nonzero), num=32)  # float32 under NumPy 2
     steps32 = np.ascontiguousarray(steps, dtype=np.float32)
     steps_d = torch.from_numpy(steps32).to(x_sorted.device)
-    ranks = torch.searchsorted(x_sorted, steps_d, right=False).cpu().numpy().astype(np.int64)  # #{w < steps[b]}
-    counts = np.diff(ranks)
+    ranks = torch.searchsorted(x_sorted, steps_d, right=False).to(torch.int64)  # #{w < steps[b]} in this shard
+    t = torch.cat([ranks, torch.tensor([stats.n_zero], dtype=torch.int64, device=x_sorted.device)])
+    if group is not None:
+        sharding.allreduce_sum_(t, group)
+    host = t.cpu().numpy()
+    counts = np.diff(host[:32])
     zero = np.float32(0.0)
     inside = np.nonzero((steps32[:-1] <= zero) & (zero < steps32[1:]))[0]
     if inside.size:
-        counts[inside[0]] -= stats.n_zero   # the zeros sit in that bin of the full vector
+        counts[inside[0]] -= int(host[32])   # the zeros sit in that bin of the full vector
     return utility._cdf_from_counts(steps, counts)
 
 
@@ -115,7 +119,14 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
     """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part."""
     x = x.reshape(-1)
     ops._require_cuda(x, "x", torch.float32)
-    n_total = x.numel() if group is None else sharding.total_count(x.numel(), x.device, group)
+    n_total = n_min = x.numel()
+    if group is not None:
+        import torch.distributed as dist
+
+        sizes = [torch.zeros(1, dtype=torch.int64, device=x.device) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(sizes, torch.tensor([x.numel()], dtype=torch.int64, device=x.device), group=group)
+        sizes = torch.cat(sizes).cpu().numpy()
+        n_total, n_min = int(sizes.sum()), int(sizes.min())
     mask = nz = sigma = thr = None
     if q is not None:
         mask, stats, nzt = prune_sharded_(x, q, std_smooth, group, n_total)
@@ -128,18 +139,18 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
     if with_cdf is None:
         with_cdf = mode == "density"
     lstats = x_sorted = None
-    if group is None and x.numel() >= _kmeans.SORT_MIN_WEIGHTS:
-        # long vector on one GPU: one statistics pass and one sort serve the weight distribution, the init and the fit
-        lstats = _kmeans.LayerStats(x)
+    if n_min >= _kmeans.SORT_MIN_WEIGHTS:
+        # long vector (every shard of it): one statistics pass and one sort serve the weight distribution, the init and the fit
+        lstats = _kmeans.LayerStats(x, n_total, group)
         x_sorted = _kmeans.sorted_copy(x, lstats)
-        cdfs = weight_distribution_sorted(x_sorted, lstats) if with_cdf else None
+        cdfs = weight_distribution_sorted(x_sorted, lstats, group) if with_cdf else None
     else:
         cdfs = weight_distribution(x, skip_zeros=True, group=group) if with_cdf else None
     if mode == "linear" and lstats is not None:
         space = np.linspace(np.float32(lstats.min), np.float32(lstats.max), num=2 ** bits).astype(np.float32)
     else:
         space = initial_centroids(x, bits, mode, cdfs, group, n_total)
-    km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted)
+    km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min)
     model, values = km.fit(want_values=want_values)
     counts = lengths = lhist = total = None
     if huffman:
