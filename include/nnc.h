@@ -156,8 +156,7 @@ typedef struct nnc_kmeans_params {
     int32_t fix_shift; /* S of the fixed-point sums, from nnc_fix_shift() */
     int32_t grid_log2; /* log2 of the number of cells of the search grid; 0 = library default */
     int32_t replicas_log2; /* log2 of LDS accumulator replicas; -1 = library default */
-    int32_t flags;     /* bit 0: the vector handed to accumulate/iterate is value-sorted (performance hint only:
-                          runs of equal cluster index go straight to global atomics; any order is still correct) */
+    int32_t flags;     /* reserved, 0 */
     float x_mean;      /* NumPy float32 mean of the whole vector */
     float tol;         /* float32(np.var(x)) * float32(1e-4) */
     float lo, hi;      /* min and max of the centred data x - x_mean (float32) */

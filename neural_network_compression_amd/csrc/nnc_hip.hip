@@ -771,8 +771,6 @@ struct KmCtx {
     const unsigned *ovf_s;   // crowded cells: first | last << 16
     unsigned long long *sum_s; // [cluster][replica] fixed-point sums
     unsigned *cnt_s;           // [cluster][replica] counts
-    long long *gsum;           // DIRECT form: this workgroup's global shard (sums), NULL otherwise
-    unsigned long long *gcnt;  // DIRECT form: global shard (counts)
     float mean, lo, inv;
     int Sft, gmax, k, rlog2, rep;
 };
@@ -850,31 +848,6 @@ __device__ __forceinline__ void km_run_flush(const KmCtx &c, KmRun &run)
     run.sum = 0;
 }
 
-// DIRECT form (value-sorted input): runs go to the global shard, aggregated per wave.  Called by
-// ALL lanes of a wave (wave-uniform branch); `need` marks the lanes whose run ends here.  Lanes
-// that end a run of the same cluster are summed with a butterfly and one lane adds the total, so
-// a workgroup crossing a cluster boundary issues a few global atomics, not one per lane.
-__device__ __forceinline__ void km_wave_flush(const KmCtx &c, KmRun &run, bool need)
-{
-    need = need && run.cnt != 0;
-    unsigned long long todo = __ballot(need);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int p0 = __shfl(run.p, leader);
-        const bool grp = need && run.p == p0;
-        const unsigned long long m = __ballot(grp);
-        long long s = grp ? run.sum : 0;
-        unsigned n = grp ? run.cnt : 0u;
-        for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); n += __shfl_xor(n, off); }
-        if ((int)(threadIdx.x & 63) == leader) {
-            atomicAdd(reinterpret_cast<unsigned long long *>(&c.gsum[p0]), (unsigned long long)s);
-            atomicAdd(&c.gcnt[p0], (unsigned long long)n);
-        }
-        if (grp) { run.cnt = 0; run.sum = 0; }
-        todo &= ~m;
-    }
-}
-
 __device__ __forceinline__ int km_cell(const KmCtx &c, float xc)
 {
     const float tt = (xc - c.lo) * c.inv;
@@ -910,55 +883,24 @@ __device__ __forceinline__ void km_accumulate(const KmCtx &c, const float (&xv)[
 // of the four hold the same single candidate, every cell between them does too (the candidate
 // ranges are monotone in the cell index), so all four weights belong to that cluster: two table
 // reads and no distance arithmetic.  On a value-sorted vector nearly every float4 takes it.
-template <int ABL, bool DIRECT>
-__device__ __forceinline__ void km_accumulate4(const KmCtx &c, const float4 v, KmRun &run, const int nvalid = 4)
+template <int ABL>
+__device__ __forceinline__ void km_accumulate4(const KmCtx &c, const float4 v, KmRun &run)
 {
     const float x0 = v.x - c.mean, x1 = v.y - c.mean, x2 = v.z - c.mean, x3 = v.w - c.mean;
     const float mn = fminf(fminf(x0, x1), fminf(x2, x3));
     const float mx = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
     const unsigned el = c.cell_s[km_cell(c, mn)];
     const unsigned eh = c.cell_s[km_cell(c, mx)];
-    if (!DIRECT) {
-        if (ABL == 0 && el == eh && (el >> KM_P_BITS) == 0) {
-            const int p = (int)el;
-            // |fix| <= 2^28, so four of them add up inside int32
-            const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
-            if (p != run.p) { km_run_flush(c, run); run.p = p; }
-            run.cnt += 4;
-            run.sum += q;
-        } else {
-            const float xv[4] = {v.x, v.y, v.z, v.w};
-            km_accumulate<4, ABL>(c, xv, run);
-        }
+    if (ABL == 0 && el == eh && (el >> KM_P_BITS) == 0) {
+        const int p = (int)el;
+        // |fix| <= 2^28, so four of them add up inside int32
+        const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
+        if (p != run.p) { km_run_flush(c, run); run.p = p; }
+        run.cnt += 4;
+        run.sum += q;
     } else {
-        // Common case: the whole float4 of a lane belongs to one cluster -> one vote per float4.
-        // Lanes whose float4 straddles a boundary (or sits in a multi-candidate cell) are handled
-        // element by element in a second, wave-uniform section.
-        const bool full = nvalid == 4;
-        const bool uniform4 = full && (el == eh) && ((el >> KM_P_BITS) == 0);
-        {
-            const int p = (int)(el & KM_P_MASK);
-            const int q = (fix_f32(x0, c.Sft) + fix_f32(x1, c.Sft)) + (fix_f32(x2, c.Sft) + fix_f32(x3, c.Sft));
-            const bool need = uniform4 && (p != run.p);
-            if (__any(need)) km_wave_flush(c, run, need);
-            if (uniform4) { run.p = p; run.cnt += 4; run.sum += q; }
-        }
-        if (__any(!uniform4 && nvalid > 0)) {
-            int p[4] = {0, 0, 0, 0};
-            if (!uniform4 && nvalid > 0) {
-                const float xv[4] = {v.x, v.y, v.z, v.w};
-                float xc[4];
-                km_resolve<4>(c, xv, xc, p);
-            }
-            const int q[4] = {fix_f32(x0, c.Sft), fix_f32(x1, c.Sft), fix_f32(x2, c.Sft), fix_f32(x3, c.Sft)};
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bool have = !uniform4 && i < nvalid;
-                const bool need = have && (p[i] != run.p);
-                if (__any(need)) km_wave_flush(c, run, need);
-                if (have) { run.p = p[i]; run.cnt += 1; run.sum += q[i]; }
-            }
-        }
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        km_accumulate<4, ABL>(c, xv, run);
     }
 }
 
@@ -1025,8 +967,8 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
 
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
 // Work split: tiles of 2 * KM_THREADS float4 (8192 weights); tile t belongs to workgroup t mod grid.
-template <int MODE, bool VEC, typename LT, int ABL = 0, bool DIRECT = false>
-__global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
+template <int MODE, bool VEC, typename LT, int ABL = 0>
+__global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out,
                                                        unsigned long long *__restrict__ dist_hist = nullptr,
@@ -1090,7 +1032,7 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
             const int novf = min(tab->n_ovf, KM_OVF_MAX);
             for (int i = threadIdx.x; i < novf; i += KM_THREADS) ovf_s[i] = tab->ovf[i];
         }
-        if (MODE == 0 && !DIRECT) {
+        if (MODE == 0) {
             const int tot = k << rlog2;
             for (int i = threadIdx.x; i < tot; i += KM_THREADS) { sum_s[i] = 0ull; cnt_s[i] = 0u; }
         }
@@ -1109,8 +1051,6 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
     c.mean = ws->p.x_mean; c.lo = ws->p.lo; c.inv = ws->inv;
     c.Sft = ws->p.fix_shift; c.gmax = G - 1; c.k = kt; c.rlog2 = rlog2;
     c.rep = threadIdx.x & ((1 << rlog2) - 1);
-    c.gsum = DIRECT ? ws->shard_sum[blockIdx.x & (KM_NSHARD - 1)] : nullptr;
-    c.gcnt = DIRECT ? ws->shard_cnt[blockIdx.x & (KM_NSHARD - 1)] : nullptr;
     KmRun run;
     run.p = -1; run.cnt = 0; run.sum = 0;
     if (trace) tr1 = __builtin_amdgcn_s_memrealtime();
@@ -1123,7 +1063,7 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
                 const float4 v = r[j];
                 r[j] = ld(cur + KM_RING);
                 if (cur < s1) {
-                    if (MODE == 0) km_accumulate4<ABL, DIRECT>(c, v, run);
+                    if (MODE == 0) km_accumulate4<ABL>(c, v, run);
                     else {
                         const float xa[4] = {v.x, v.y, v.z, v.w};
                         km_emit<4, LT>(c, xa, 4 * (cur * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out, hist_s, hr);
@@ -1135,28 +1075,11 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
     // ragged end (less than one step of float4s, then the scalars): last workgroup
     if (blockIdx.x == gridDim.x - 1) {
         const int64_t vdone = nsteps * KM_THREADS;
-        if (MODE == 0 && DIRECT) {
-            // every lane runs every round (the flush votes are wave-wide); lanes past the end carry no element
-            const int64_t vrounds = (nvec - vdone + KM_THREADS - 1) / KM_THREADS;
-            for (int64_t r = 0; r < vrounds; r++) {
-                const int64_t v = vdone + r * KM_THREADS + threadIdx.x;
-                const bool have = v < nvec;
-                const float4 a4 = have ? x4[v] : make_float4(0.f, 0.f, 0.f, 0.f);
-                km_accumulate4<ABL, DIRECT>(c, a4, run, have ? 4 : 0);
-            }
-            const int64_t sbase = nvec << 2;
-            const int64_t srounds = (n - sbase + KM_THREADS - 1) / KM_THREADS;
-            for (int64_t r = 0; r < srounds; r++) {
-                const int64_t i = sbase + r * KM_THREADS + threadIdx.x;
-                const bool have = i < n;
-                const float xv = have ? x[i] : 0.0f;
-                km_accumulate4<ABL, DIRECT>(c, make_float4(xv, xv, xv, xv), run, have ? 1 : 0);
-            }
-        } else {
+        {
             for (int64_t v = vdone + threadIdx.x; v < nvec; v += KM_THREADS) {
                 const float4 a4 = x4[v];
                 const float xa[4] = {a4.x, a4.y, a4.z, a4.w};
-                if (MODE == 0) km_accumulate4<ABL, DIRECT>(c, a4, run);
+                if (MODE == 0) km_accumulate4<ABL>(c, a4, run);
                 else km_emit<4, LT>(c, xa, 4 * v, labels_out, quant_out, dist_out, hist_s, hr);
             }
             // scalars: fewer than 4 when the input is 16-byte aligned; the whole vector otherwise
@@ -1169,12 +1092,9 @@ __global__ __launch_bounds__(KM_THREADS, (DIRECT ? 4 : 8)) void k_assign(const f
     }
     if (trace) tr2 = __builtin_amdgcn_s_memrealtime();
     if (MODE == 0) {
-        if (DIRECT) km_wave_flush(c, run, true);
-        else {
-            if (ABL != 1 && ABL != 3) km_run_flush(c, run);
-            else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
-            km_flush(c, ws);
-        }
+        if (ABL != 1 && ABL != 3) km_run_flush(c, run);
+        else if (run.sum == 0x7fffffffffffll) sum_s[0] = run.sum; // keep the ablated arithmetic alive
+        km_flush(c, ws);
     }
     if (MODE == 1 && hist_s) {
         if (hr.cnt) atomicAdd(&hist_s[hr.bin], hr.cnt);
@@ -1725,12 +1645,11 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     return km_launch_finalize(w, FIN_INIT, 0, stream);
 }
 
-static int km_grid(int64_t n, size_t lds_bytes, bool one_per_cu = false)
+static int km_grid(int64_t n, size_t lds_bytes)
 {
     int64_t blocks = ((n + 7) / 8 + KM_THREADS - 1) / KM_THREADS;
     if (blocks < 1) blocks = 1;
     int per_cu = (lds_bytes + 1024 <= 80 * 1024) ? 2 : 1; // two 1024-thread workgroups fit a CU if LDS allows
-    if (one_per_cu) per_cu = 1;                            // ... and registers (the DIRECT form needs more than 64)
     static int mult_q = -1; // tuning knob: workgroups per resident slot, in quarters (NNC_KM_GRID_QUARTERS)
     if (mult_q < 0) { const char *e = getenv("NNC_KM_GRID_QUARTERS"); mult_q = e ? atoi(e) : 4; if (mult_q < 1) mult_q = 4; }
     return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu * mult_q / 4);
@@ -1818,9 +1737,9 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
 {
     int glog2, rlog2;
     km_defaults(p, &glog2, &rlog2);
-    size_t lds = km_lds_bytes(p->k, glog2, rlog2, (p->flags & 1) == 0);
+    size_t lds = km_lds_bytes(p->k, glog2, rlog2, true);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    int grid = km_grid(p->n, lds, vec && (p->flags & 1) != 0 && g_ablation == 0);
+    int grid = km_grid(p->n, lds);
     if (p->n == 0) return NNC_OK;
     const bool prof = g_prof_on && g_prof_used < g_prof_pool.size();
     if (g_prof_on && !prof) g_prof_skipped++;
@@ -1829,9 +1748,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
     hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
 #define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, which, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr)
-    const bool direct = (p->flags & 1) != 0; // caller promises long runs of equal cluster index (value-sorted input)
-    if (vec && direct && g_ablation == 0) KM_LAUNCH_ACC(true, uint8_t, 0, true);
-    else if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
+    if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
     else if (vec && g_ablation == 2) KM_LAUNCH_ACC(true, uint8_t, 2);
     else if (vec && g_ablation == 3) KM_LAUNCH_ACC(true, uint8_t, 3);
     else if (vec) KM_LAUNCH_ACC(true, uint8_t);
@@ -1849,7 +1766,6 @@ static int km_set_lds_attr()
     const int maxlds = 160 * 1024;
 #define SETATTR(fn) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds))
     SETATTR((k_assign<0, true, uint8_t>));
-    SETATTR((k_assign<0, true, uint8_t, 0, true>));
     SETATTR((k_assign<0, true, uint8_t, 1>));
     SETATTR((k_assign<0, true, uint8_t, 2>));
     SETATTR((k_assign<0, true, uint8_t, 3>));
