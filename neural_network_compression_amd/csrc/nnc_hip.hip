@@ -130,17 +130,31 @@ __device__ __forceinline__ float xform1(float v, float mean)
     return v;
 }
 
-// one wave per full chunk; 4 waves (4 chunks) per workgroup
+// The ragged last chunk (m < 8192 elements): the generic workgroup-parallel pairwise sum.
+struct PwFrame { int start, len, stage; float left; };
+struct PwHeap { int start[256]; int len[256]; float val[256]; };
+template <typename F> __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp);
+
+// one wave per full chunk; 4 waves (4 chunks) per workgroup; with a ragged last chunk the grid has one more
+// workgroup, which sums it (so that it runs beside the others instead of in a launch of its own)
 template <bool SQDEV, bool VEC>
 __global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x, int64_t nfull,
                                                     const float *__restrict__ mean_dev,
-                                                    float *__restrict__ out)
+                                                    float *__restrict__ out, int tail)
 {
     __shared__ __align__(16) float lds[4][8 * LEAF_PAD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *my = lds[wave];
     const float mean = SQDEV ? *mean_dev : 0.0f;
-    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nfull; chunk += (int64_t)gridDim.x * 4) {
+    const int64_t gmain = (int64_t)gridDim.x - (tail > 0 ? 1 : 0); // workgroups that take full chunks
+    if (tail > 0 && blockIdx.x == gridDim.x - 1) {
+        __shared__ PwHeap heap;
+        const float *xt = x + nfull * NNC_CHUNK;
+        const float r = block_pairwise_sum([&](int i) { return xform1<SQDEV>(xt[i], mean); }, tail, &heap);
+        if (threadIdx.x == 0) out[nfull] = r;
+        return;
+    }
+    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nfull; chunk += gmain * 4) {
         const float *base = x + chunk * NNC_CHUNK;
         float node[8];
         float4 cur[4], nxt[4];
@@ -191,16 +205,6 @@ __global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x,
     }
 }
 
-// The ragged last chunk (m < 8192 elements): the generic workgroup-parallel pairwise sum.
-struct PwFrame { int start, len, stage; float left; };
-struct PwHeap;
-template <typename F> __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp);
-
-template <bool SQDEV>
-__global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x, int m,
-                                                    const float *__restrict__ mean_dev,
-                                                    float *__restrict__ out);
-
 extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const float *mean_dev,
                                   float *chunk_out, void *stream)
 {
@@ -210,23 +214,18 @@ extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const fl
     const int64_t nfull = n / NNC_CHUNK;
     const int tail = (int)(n % NNC_CHUNK);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (nfull > 0) {
+    {
         int64_t blocks = (nfull + 3) / 4;
         int64_t cap = (int64_t)cu_count() * 8;
-        int grid = (int)std::min<int64_t>(blocks, cap);
+        int grid = (int)std::min<int64_t>(blocks, cap) + (tail > 0 ? 1 : 0);
         if (sqdev) {
-            if (vec) hipLaunchKernelGGL((k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
-            else hipLaunchKernelGGL((k_chunk_sums<true, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
+            if (vec) hipLaunchKernelGGL((k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
+            else hipLaunchKernelGGL((k_chunk_sums<true, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
         } else {
-            if (vec) hipLaunchKernelGGL((k_chunk_sums<false, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
-            else hipLaunchKernelGGL((k_chunk_sums<false, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out);
+            if (vec) hipLaunchKernelGGL((k_chunk_sums<false, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
+            else hipLaunchKernelGGL((k_chunk_sums<false, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
         }
         LAUNCHCHK("k_chunk_sums");
-    }
-    if (tail > 0) {
-        if (sqdev) hipLaunchKernelGGL((k_chunk_tail<true>), dim3(1), dim3(256), 0, S(stream), x + nfull * NNC_CHUNK, tail, mean_dev, chunk_out + nfull);
-        else hipLaunchKernelGGL((k_chunk_tail<false>), dim3(1), dim3(256), 0, S(stream), x + nfull * NNC_CHUNK, tail, mean_dev, chunk_out + nfull);
-        LAUNCHCHK("k_chunk_tail");
     }
     return NNC_OK;
 }
@@ -1113,7 +1112,6 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
 // split tree (n/2 rounded down to a multiple of 8, leaves of <= 128) is laid out as a binary
 // heap in LDS (node i -> children 2i, 2i+1; depth <= 7), leaves are summed by 8 lanes each, and
 // the tree is folded level by level.  F(i) returns element i.  All threads get the result.
-struct PwHeap { int start[256]; int len[256]; float val[256]; };
 
 template <typename F>
 __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
@@ -1170,18 +1168,6 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
     return hp->val[1];
 }
 
-template <bool SQDEV>
-__global__ __launch_bounds__(256) void k_chunk_tail(const float *__restrict__ x, int m,
-                                                    const float *__restrict__ mean_dev,
-                                                    float *__restrict__ out)
-{
-    __shared__ PwHeap heap;
-    const float mean = SQDEV ? *mean_dev : 0.0f;
-    const float r = block_pairwise_sum([&](int i) { return xform1<SQDEV>(x[i], mean); }, m, &heap);
-    if (threadIdx.x == 0) *out = r;
-}
-template __global__ void k_chunk_tail<true>(const float *, int, const float *, float *);
-template __global__ void k_chunk_tail<false>(const float *, int, const float *, float *);
 
 // ---- finalize / prepare kernel (one workgroup) -------------------------------------------
 #define FIN_INIT 0          // build the table for the initial centres

@@ -52,6 +52,6 @@ timeit("sorted copy", lambda: kmeans.sorted_copy(x, km.stats), bytes_=4 * n)
 timeit("assign labels+values", lambda: km.assign(0, True, True, False), bytes_=9 * n)
 timeit("assign labels+dist", lambda: km.assign(0, True, False, True), bytes_=9 * n)
 lab, _, d = km.assign(0, True, False, True)
-timeit("local_top_keys m=150", lambda: km._local_top_keys(d, 150, 0))
+timeit("top_keys m=150", lambda: km._top_keys(d, x, 150))
 timeit("bincount", lambda: ops.bincount(lab, 256), bytes_=n)
 timeit("iterate(1) (assign+finalize)", lambda: km.iterate(1))
