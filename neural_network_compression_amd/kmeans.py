@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 import time
 
 import numpy as np
@@ -189,9 +190,13 @@ class DeviceKMeans:
             raise ValueError("reloc must be 'auto' or 'full'")
         self.reloc = reloc
         # pinned host landing zones for the small device->host reads (status block, 4096-bin histogram)
-        self._status_pin = torch.zeros(ctypes.sizeof(nat.KMeansStatus) + 8, dtype=torch.uint8, pin_memory=True)
-        self._status_host = nat.KMeansStatus.from_address(self._status_pin.data_ptr())
-        self._ticket_host = ctypes.c_uint64.from_address(self._status_pin.data_ptr() + ctypes.sizeof(nat.KMeansStatus))
+        # two slots of (status block, ticket): a look-in alternates between them, so that one may still be in flight
+        # (published behind a speculative batch) while the host reads the other
+        ssz = ctypes.sizeof(nat.KMeansStatus) + 8
+        self._status_pin = torch.zeros(2 * ssz, dtype=torch.uint8, pin_memory=True)
+        self._slot_addr = [self._status_pin.data_ptr() + i * ssz for i in range(2)]
+        self._slot_status = [nat.KMeansStatus.from_address(a) for a in self._slot_addr]
+        self._slot_ticket = [ctypes.c_uint64.from_address(a + ctypes.sizeof(nat.KMeansStatus)) for a in self._slot_addr]
         self._ticket = 0
         self._hist_pin = torch.empty(4096, dtype=torch.int64, pin_memory=True)
         # The iterations stream a value-sorted copy (same sums in any order, far fewer LDS atomics);
@@ -209,25 +214,30 @@ class DeviceKMeans:
             self.x_iter = sorted_copy(x, stats) if self.sorted else x
 
     # -------------------------------------------------------------- low-level steps
-    def status(self) -> nat.KMeansStatus:
-        """The device state after everything enqueued so far.  A one-thread kernel writes it into pinned host
-        memory followed by a ticket; polling that word costs a few microseconds less than a copy command plus a
-        stream synchronisation, and the fit looks in dozens of times."""
+    def publish(self) -> int:
+        """Enqueue a look-in: a one-thread kernel writes the status block into pinned host memory, then a ticket.
+        Returns the ticket; wait(ticket) polls for it.  (A few microseconds instead of a copy command plus a stream
+        synchronisation; and the host may enqueue more work before it waits.)  At most two may be outstanding."""
         self._ticket += 1
-        nat.check(self.L.nnc_kmeans_status_publish(self.ws.data_ptr(), self._status_pin.data_ptr(), self._ticket, self.stream))
-        t = self._ticket_host
-        want = self._ticket
+        nat.check(self.L.nnc_kmeans_status_publish(self.ws.data_ptr(), self._slot_addr[self._ticket & 1], self._ticket, self.stream))
+        return self._ticket
+
+    def wait(self, ticket: int) -> nat.KMeansStatus:
+        t = self._slot_ticket[ticket & 1]
         spins = 0
-        while t.value != want:
+        while t.value != ticket:
             spins += 1
-            if spins & 0xFFFFF == 0:   # every million polls: a dead stream must not hang the host
-                if time.monotonic() - self._spin_t0 > 60.0:
-                    torch.cuda.current_stream(self.dev).synchronize()   # surfaces the device error, if any
-                    if t.value != want:
-                        raise RuntimeError("k-means status never arrived")
-            elif spins == 1:
-                self._spin_t0 = time.monotonic()
-        return self._status_host
+            if spins == 1:
+                t0 = time.monotonic()
+            elif spins & 0xFFFFF == 0 and time.monotonic() - t0 > 60.0:   # a dead stream must not hang the host
+                torch.cuda.current_stream(self.dev).synchronize()          # surfaces the device error, if any
+                if t.value != ticket:
+                    raise RuntimeError("k-means status never arrived")
+        return self._slot_status[ticket & 1]
+
+    def status(self) -> nat.KMeansStatus:
+        """The device state after everything enqueued so far."""
+        return self.wait(self.publish())
 
     def iterate(self, iters: int):
         """Enqueue `iters` Lloyd iterations (no host sync)."""
@@ -399,28 +409,47 @@ class DeviceKMeans:
         strict_labels = None
         batch = 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
+        # NNC_KM_AHEAD=1 (experiment, off): keep one batch enqueued AHEAD of the look-in the host is waiting for, so
+        # that the GPU iterates while the host decides.  Measured 0.1 ms per step SLOWER on the bench workload: when
+        # the status says paused or done the batch ahead is a row of no-ops, and a no-op iteration (first loads of
+        # the streaming kernel, finalize, cells, look-in) costs about what the idle gap did.
+        ahead = self.group is None and os.environ.get("NNC_KM_AHEAD", "0") == "1"
+        self.iterate(batch)
+        tickets = [self.publish()]
         while True:
-            self.iterate(batch)
-            st = self.status()
+            in_flight = 0
+            if ahead and len(tickets) < 2:
+                self.iterate(batch)
+                tickets.append(self.publish())
+                in_flight = batch
+            st = self.wait(tickets.pop(0))
             if st.done:
                 break
             if st.paused:
-                # an empty cluster stopped the device loop inside this batch: relocate and resume that
-                # iteration on the device, then go on one iteration at a time for a while.  No look-in
-                # in between: if the resumed iteration was the last one the next launch is a no-op.
+                # an empty cluster stopped the device loop inside this batch (anything enqueued behind it is a
+                # no-op and its look-in is of no interest): relocate and resume that iteration on the device, then
+                # go on one iteration at a time for a while
+                tickets.clear()
                 self._relocate_and_resume(st)
                 batch = 1
                 hist = []
+                self.iterate(batch)
+                tickets.append(self.publish())
                 continue
             # size the next batch so that it ends about where the shift crosses the tolerance
             # (launches enqueued after convergence are no-ops, but they still cost a dispatch)
-            hist.append((int(st.iter), float(st.shift_tot)))
+            if not hist or int(st.iter) > hist[-1][0]:
+                hist.append((int(st.iter), float(st.shift_tot)))
             batch = min(self.batch, batch * 2)
             if len(hist) >= 2 and hist[-1][1] > 0 and hist[-2][1] > hist[-1][1] and self.tol_ > 0:
                 (i0, s0), (i1, s1) = hist[-2], hist[-1]
                 rate = math.log(s0 / s1) / max(1, i1 - i0)          # log-decay per iteration
                 left = math.log(s1 / float(self.tol_)) / rate if s1 > float(self.tol_) else 0.0
+                left -= in_flight   # the batch already enqueued ahead counts against what is left
                 batch = int(max(1, min(self.batch, math.floor(left * 0.9))))
+            if not tickets:
+                self.iterate(batch)
+                tickets.append(self.publish())
         if int(st.done) == 3:
             # strict stop: keep the labels of that iteration = E-step on the centres it started
             # from, which the resumed finalize has made the "previous" set
