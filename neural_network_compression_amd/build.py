@@ -35,14 +35,18 @@ def is_stale() -> bool:
 def build_native(force: bool = False, verbose: bool = False) -> str:
     if not force and not is_stale():
         return LIB
+    tmp = f"{LIB}.{os.getpid()}.tmp"   # built aside and renamed: another process never maps a half-written library
     cmd = [
         hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17",
         "-ffp-contract=off",  # the reference arithmetic is unfused float32; never contract
-        "-fPIC", "-shared", "-I", INCLUDE, "-o", LIB,
+        "-fPIC", "-shared", "-I", INCLUDE, "-o", tmp,
     ] + SOURCES
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+    os.replace(tmp, LIB)
     if verbose:
         print(proc.stdout + proc.stderr)
     return LIB
