@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--cpu-sample", type=int, default=16_000_000)
     ap.add_argument("--dump-durations", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
+                                                      "the multi-rank path with all ranks on one GPU: --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -105,6 +108,8 @@ def main():
         if rank == 0 and world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     group = None
@@ -112,7 +117,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
         group = dist.group.WORLD
 
     from neural_network_compression_amd import _native as nat
