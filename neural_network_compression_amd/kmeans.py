@@ -269,10 +269,13 @@ class DeviceKMeans:
                                            ops._ptr(lab), lb, ops._ptr(q), ops._ptr(d), ops._ptr(dist_hist), self.stream))
         return lab, q, d
 
-    def centers(self, which: int = 0, centred: bool = False) -> np.ndarray:
+    def centers_device(self, which: int = 0, centred: bool = False) -> torch.Tensor:
         out = torch.empty(self.k, dtype=torch.float32, device=self.dev)
         nat.check(self.L.nnc_kmeans_get_centers(self.ws.data_ptr(), int(which), 1 if centred else 0, out.data_ptr(), self.stream))
-        return out.cpu().numpy()
+        return out
+
+    def centers(self, which: int = 0, centred: bool = False) -> np.ndarray:
+        return self.centers_device(which, centred).cpu().numpy()
 
     # -------------------------------------------------------------- empty-cluster relocation
     TOPM_CAP = 1 << 16
@@ -455,7 +458,8 @@ class DeviceKMeans:
             # from, which the resumed finalize has made the "previous" set
             strict_labels = self.assign(which=1, labels=True)[0]
         stop = {1: "tol", 2: "max_iter", 3: "strict"}.get(int(st.done), "?")
-        centers = self.centers(which=0, centred=False)
+        n_iter = int(st.iter)
+        cen_d = self.centers_device(which=0, centred=False)
         if strict_labels is not None:
             # label-equality stop: scikit-learn keeps the labels of that iteration and does
             # not run another E-step (_kmeans.py:717-722, 736)
@@ -463,14 +467,15 @@ class DeviceKMeans:
             vals = None
             if want_values:
                 idx = lab.to(torch.int64) if lab.dtype == torch.uint8 else (lab.to(torch.int64) & 0xFFFF)
-                vals = torch.from_numpy(centers).to(self.dev)[idx]
+                vals = cen_d[idx]
         else:
             lab, vals, _ = self.assign(which=0, labels=True, values=want_values)
-        model = QuantizedModel(centers, lab, st.iter, self.n_relocations, stop)
         # index histogram of these labels (this rank's shard), from one more pass over the iteration copy
         counts = torch.empty(self.k, dtype=torch.int64, device=self.dev)
         nat.check(self.L.nnc_kmeans_label_counts(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
                                                  1 if strict_labels is not None else 0, counts.data_ptr(), self.stream))
+        centers = cen_d.cpu().numpy()   # the one host read of the epilogue, behind everything that was enqueued
+        model = QuantizedModel(centers, lab, n_iter, self.n_relocations, stop)
         model.counts_device_ = counts
         model.n_reloc_windowed_ = self.n_reloc_windowed   # relocation events settled without a pass over the vector
         return model, vals

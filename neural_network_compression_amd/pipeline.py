@@ -153,15 +153,26 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
     km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min)
     model, values = km.fit(want_values=want_values)
     counts = lengths = lhist = total = None
+    counts_d = None
     if huffman:
         counts_d = getattr(model, "counts_device_", None)
         if counts_d is None:
             counts_d = ops.bincount(model.labels_compact_, km.k)
         if group is not None:
             sharding.allreduce_sum_(counts_d, group)
-        counts = counts_d.cpu().numpy()
-        lengths, lhist, total = ops.huffman_lengths(counts)
+    # one host read for what is left on the device: index histogram, sigma / threshold (two float32 carried as one
+    # int64), number of zeroed weights
+    parts = []
+    if counts_d is not None:
+        parts.append(counts_d.reshape(-1))
     if q is not None:
-        s = stats.cpu().numpy()
-        sigma, thr, nz = float(s[0]), float(s[1]), int(nzt.item())
+        parts += [stats.reshape(-1)[:2].contiguous().view(torch.int64), nzt.reshape(-1)[:1]]
+    if parts:
+        host = torch.cat(parts).cpu().numpy()
+        if counts_d is not None:
+            counts = host[: km.k].copy()
+            lengths, lhist, total = ops.huffman_lengths(counts)
+        if q is not None:
+            sf = host[-2:-1].view(np.float32)
+            sigma, thr, nz = float(sf[0]), float(sf[1]), int(host[-1])
     return LayerResult(mask, nz, sigma, thr, values, model, counts, lengths, lhist, total)
