@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import ctypes
 import math
-import os
 import time
 
 import numpy as np
@@ -412,47 +411,28 @@ class DeviceKMeans:
         strict_labels = None
         batch = 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
-        # NNC_KM_AHEAD=1 (experiment, off): keep one batch enqueued AHEAD of the look-in the host is waiting for, so
-        # that the GPU iterates while the host decides.  Measured 0.1 ms per step SLOWER on the bench workload: when
-        # the status says paused or done the batch ahead is a row of no-ops, and a no-op iteration (first loads of
-        # the streaming kernel, finalize, cells, look-in) costs about what the idle gap did.
-        ahead = self.group is None and os.environ.get("NNC_KM_AHEAD", "0") == "1"
-        self.iterate(batch)
-        tickets = [self.publish()]
         while True:
-            in_flight = 0
-            if ahead and len(tickets) < 2:
-                self.iterate(batch)
-                tickets.append(self.publish())
-                in_flight = batch
-            st = self.wait(tickets.pop(0))
+            self.iterate(batch)
+            st = self.status()
             if st.done:
                 break
             if st.paused:
-                # an empty cluster stopped the device loop inside this batch (anything enqueued behind it is a
-                # no-op and its look-in is of no interest): relocate and resume that iteration on the device, then
-                # go on one iteration at a time for a while
-                tickets.clear()
+                # an empty cluster stopped the device loop inside this batch: relocate and resume that
+                # iteration on the device, then go on one iteration at a time for a while.  No look-in
+                # in between: if the resumed iteration was the last one the next launch is a no-op.
                 self._relocate_and_resume(st)
                 batch = 1
                 hist = []
-                self.iterate(batch)
-                tickets.append(self.publish())
                 continue
             # size the next batch so that it ends about where the shift crosses the tolerance
             # (launches enqueued after convergence are no-ops, but they still cost a dispatch)
-            if not hist or int(st.iter) > hist[-1][0]:
-                hist.append((int(st.iter), float(st.shift_tot)))
+            hist.append((int(st.iter), float(st.shift_tot)))
             batch = min(self.batch, batch * 2)
             if len(hist) >= 2 and hist[-1][1] > 0 and hist[-2][1] > hist[-1][1] and self.tol_ > 0:
                 (i0, s0), (i1, s1) = hist[-2], hist[-1]
                 rate = math.log(s0 / s1) / max(1, i1 - i0)          # log-decay per iteration
                 left = math.log(s1 / float(self.tol_)) / rate if s1 > float(self.tol_) else 0.0
-                left -= in_flight   # the batch already enqueued ahead counts against what is left
                 batch = int(max(1, min(self.batch, math.floor(left * 0.9))))
-            if not tickets:
-                self.iterate(batch)
-                tickets.append(self.publish())
         if int(st.done) == 3:
             # strict stop: keep the labels of that iteration = E-step on the centres it started
             # from, which the resumed finalize has made the "previous" set
