@@ -16,6 +16,7 @@ import torch
 
 from .common.trainer import LeNetDataset
 from .le_net_300_100_trainer import LeNet300100Trainer
+from .le_net_5_trainer import LeNet5Trainer
 
 
 def reset_seed() -> None:
@@ -61,7 +62,26 @@ def run_experiment_with_lenet300100(train_epochs: int, prune_train_epochs: int, 
                                     with_cumulative_weight_distribution: bool, experiment_name: str) -> None:
     reset_seed()
     train_dataset, test_dataset = get_train_and_test_dataset()
-    trainer = LeNet300100Trainer()
+    _run_experiment(LeNet300100Trainer(), train_dataset, test_dataset, train_epochs, prune_train_epochs,
+                    semi_prune_train_epochs, maximum_centroid_bits, k_means_initialization_mode,
+                    with_cumulative_weight_distribution, experiment_name)
+
+
+def run_experiment_with_lenet5(train_epochs: int, prune_train_epochs: int, semi_prune_train_epochs: int,
+                               maximum_centroid_bits: int, k_means_initialization_mode: str,
+                               with_cumulative_weight_distribution: bool, experiment_name: str) -> None:
+    """The same experiment on LeNet-5 (the reference's README lists it as a TODO): images as (N, 28, 28, 1)."""
+    reset_seed()
+    train_dataset, test_dataset = get_train_and_test_dataset()
+    as_images = lambda d: LeNetDataset(np.asarray(d.input_data).reshape(-1, 28, 28, 1), d.output_data)  # noqa: E731
+    _run_experiment(LeNet5Trainer(), as_images(train_dataset), as_images(test_dataset), train_epochs, prune_train_epochs,
+                    semi_prune_train_epochs, maximum_centroid_bits, k_means_initialization_mode,
+                    with_cumulative_weight_distribution, experiment_name)
+
+
+def _run_experiment(trainer, train_dataset, test_dataset, train_epochs, prune_train_epochs, semi_prune_train_epochs,
+                    maximum_centroid_bits, k_means_initialization_mode, with_cumulative_weight_distribution,
+                    experiment_name) -> None:
     report_directory = f"{trainer.model_name}_{experiment_name}"
 
     train_accuracies = trainer.train(train_dataset=train_dataset, test_dataset=test_dataset, epochs=train_epochs)

@@ -42,10 +42,14 @@ class Dense(KerasLikeLayer):
 
 
 class Conv2D(KerasLikeLayer):
-    """'valid' convolution, NHWC input, kernel stored (h, w, in, out) as Keras does."""
+    """Convolution with Keras' padding "valid" or "same" (odd kernels), NHWC input, kernel stored
+    (h, w, in, out) as Keras does."""
 
-    def __init__(self, in_channels: int, filters: int, kernel_size: int, activation=None):
+    def __init__(self, in_channels: int, filters: int, kernel_size: int, activation=None, padding: str = "valid"):
         super().__init__()
+        if padding not in ("valid", "same"):
+            raise ValueError("padding must be 'valid' or 'same'")
+        self.pad = kernel_size // 2 if padding == "same" else 0
         fan_in, fan_out = kernel_size * kernel_size * in_channels, kernel_size * kernel_size * filters
         limit = math.sqrt(6.0 / (fan_in + fan_out))
         self.kernel = nn.Parameter(torch.empty(kernel_size, kernel_size, in_channels, filters).uniform_(-limit, limit))
@@ -53,7 +57,7 @@ class Conv2D(KerasLikeLayer):
         self.activation = activation
 
     def forward(self, x):  # x: (N, H, W, C)
-        y = F.conv2d(x.permute(0, 3, 1, 2), self.kernel.permute(3, 2, 0, 1), self.bias)
+        y = F.conv2d(x.permute(0, 3, 1, 2), self.kernel.permute(3, 2, 0, 1), self.bias, padding=self.pad)
         y = y.permute(0, 2, 3, 1)
         return self.activation(y) if self.activation is not None else y
 

@@ -153,3 +153,51 @@ def test_sharded_code_path_with_one_rank_group(trainer_mod):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_lenet5_trainer_prune_and_quantize_match_oracle(trainer_mod):
+    """BASELINE configs[2]: LeNet-5 conv + dense tensors (Keras layouts), prune at (1, 0.1) sigma, 5-bit forgy
+    k-means; the tensors too short for 32 centroids pass through.  Layer by layer against the oracle."""
+    _, tr, main, _ = trainer_mod
+    from neural_network_compression_amd import le_net_5_trainer
+    tr.Trainer.pruned_indexes_by_layer.clear()
+    t = le_net_5_trainer.LeNet5Trainer()
+    ws = {}
+    attr = {"conv1": "conv1", "conv2": "conv2", "dense1": "dense", "out": "logits"}   # synth's names -> the reference's
+    for li, (sname, wshape, bshape) in enumerate(synth.LENET_5):
+        name = attr[sname]
+        layer = getattr(t.neural_network, name)
+        w = synth.weights(wshape, 3000 + 2 * li)
+        b = synth.weights(bshape, 3000 + 2 * li + 1)
+        layer.set_weights([torch.from_numpy(w).cuda(), torch.from_numpy(b).cuda()])
+        ws[name] = (w, b)
+    t._prune_parameters(True)
+    q = {"conv1": (1, 0.1), "conv2": (1, 0.1), "dense": (1, 0.1), "logits": (0.5, 0)}
+    for name, (w, b) in ws.items():
+        mw, mb = t.pruned_indexes_by_layer[getattr(t.neural_network, name)]
+        assert np.array_equal(mw.cpu().numpy(), orc.prune_weigth(w.copy(), q[name][0], True))
+        assert np.array_equal(mb.cpu().numpy(), orc.prune_weigth(b.copy(), q[name][1], True))
+    test = tr.LeNetDataset(np.random.RandomState(0).rand(16, 28, 28, 1).astype(np.float32), np.zeros(16, dtype=np.int64))
+    np.random.seed(77)
+    acc = t.quantize(test, False, 5, "forgy")
+    assert 0.0 <= acc <= 1.0
+    np.random.seed(77)   # the oracle draws the same forgy indices in the same tensor order
+    for name, (w, b) in ws.items():
+        layer = getattr(t.neural_network, name)
+        for got, ref, qq in zip(layer.get_weights(), (w.copy(), b.copy()), q[name]):
+            orc.prune_weigth(ref, qq, True)
+            want, km = orc.get_quantized_weight(ref.copy(), bits=5, mode="forgy", cdfs=None, accum="B")
+            assert np.array_equal(got.cpu().numpy(), want), (name, ref.shape)
+            assert (km is None) == (ref.size < 33)
+
+
+def test_run_experiment_lenet5_surface(trainer_mod, tmp_path, monkeypatch):
+    _, tr, main, _ = trainer_mod
+    tr.Trainer.pruned_indexes_by_layer.clear()
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(main, "_synthetic", lambda n_train=1024, n_test=256, _f=main._synthetic: _f(n_train, n_test))
+    main.run_experiment_with_lenet5(train_epochs=1, prune_train_epochs=1, semi_prune_train_epochs=1,
+                                    maximum_centroid_bits=3, k_means_initialization_mode="linear",
+                                    with_cumulative_weight_distribution=False, experiment_name="smoke")
+    rep = (tmp_path / "LeNet5_smoke" / "report.txt").read_text()
+    assert "layer: conv1" in rep and "layer: dense" in rep and "layer: logits" in rep
