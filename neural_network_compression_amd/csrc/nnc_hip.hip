@@ -966,7 +966,7 @@ __device__ __forceinline__ void km_emit(const KmCtx &c, const float (&xv)[B], in
 
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
 // Work split: tiles of 2 * KM_THREADS float4 (8192 weights); tile t belongs to workgroup t mod grid.
-template <int MODE, bool VEC, typename LT, int ABL = 0>
+template <int MODE, bool VEC, typename LT, int ABL = 0, bool DEAL = false>
 __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restrict__ x, int64_t n, KmWs *__restrict__ ws,
                                                        int which, LT *__restrict__ labels_out,
                                                        float *__restrict__ quant_out, float *__restrict__ dist_out,
@@ -985,16 +985,26 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     // tables come from L2 while HBM is already streaming).
     const int64_t nvec = VEC ? (n >> 2) : 0;
     const int64_t nsteps = nvec / KM_THREADS;
-    const int64_t per = (nsteps + gridDim.x - 1) / gridDim.x;
-    const int64_t s0 = (int64_t)blockIdx.x * per;
-    const int64_t s1 = (s0 + per < nsteps) ? (s0 + per) : nsteps;
+    // DEAL (accumulate on a value-sorted vector): the outermost grid/2 steps at either end are dealt one to a workgroup,
+    // the rest is split into contiguous ranges.  The tails are where clusters are narrowest -- right after a mass
+    // relocation dozens of one-sample clusters sit there and every weight takes the general path -- so no single
+    // workgroup should own a tail.  (The host picks DEAL only if nsteps >= 4 * grid and the grid is even.)
+    const int64_t tails = DEAL ? (int64_t)(gridDim.x >> 1) : 0;
+    const int64_t nmain = nsteps - 2 * tails;
+    const int64_t per = (nmain + gridDim.x - 1) / gridDim.x;
+    int64_t s0 = tails + (int64_t)blockIdx.x * per;
+    const int64_t mend = nsteps - tails;
+    if (s0 > mend) s0 = mend;
+    const int64_t s1 = (s0 + per < mend) ? (s0 + per) : mend;
+    const int64_t dealt = DEAL ? (((int64_t)blockIdx.x < tails) ? (int64_t)blockIdx.x : nsteps - 1 - ((int64_t)blockIdx.x - tails)) : 0;
+    const int64_t count = (s1 - s0) + (DEAL ? 1 : 0); // steps of this workgroup: [dealt,] s0 .. s1-1
+    auto step_of = [&](int64_t kk) -> int64_t { return DEAL ? (kk == 0 ? dealt : s0 + kk - 1) : s0 + kk; };
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     const float4 *base = x4 + threadIdx.x;
-    const int64_t last = s1 - 1;
-    auto ld = [&](int64_t st) -> float4 { return st <= last ? base[st * KM_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f); };
+    auto ld = [&](int64_t kk) -> float4 { return kk < count ? base[step_of(kk) * KM_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f); };
     float4 r[KM_RING];
 #pragma unroll
-    for (int j = 0; j < KM_RING; j++) r[j] = ld(s0 + j);
+    for (int j = 0; j < KM_RING; j++) r[j] = ld(j);
 
     if (MODE == 0 && !(which & 2) && (ws->st.done | ws->st.paused)) return; // (which & 2: counting pass after the fit, see nnc_kmeans_label_counts)
     if (MODE == 1 && n_dev && s0 >= s1 && blockIdx.x != gridDim.x - 1) return; // nothing in this workgroup's range
@@ -1054,19 +1064,17 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     run.p = -1; run.cnt = 0; run.sum = 0;
     if (trace) tr1 = __builtin_amdgcn_s_memrealtime();
 
-    if (s0 < s1) {
-        for (int64_t st = s0; st < s1; st += KM_RING) {
+    for (int64_t kk = 0; kk < count; kk += KM_RING) {
 #pragma unroll
-            for (int j = 0; j < KM_RING; j++) {
-                const int64_t cur = st + j;
-                const float4 v = r[j];
-                r[j] = ld(cur + KM_RING);
-                if (cur < s1) {
-                    if (MODE == 0) km_accumulate4<ABL>(c, v, run);
-                    else {
-                        const float xa[4] = {v.x, v.y, v.z, v.w};
-                        km_emit<4, LT>(c, xa, 4 * (cur * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out, hist_s, hr);
-                    }
+        for (int j = 0; j < KM_RING; j++) {
+            const int64_t kcur = kk + j;
+            const float4 v = r[j];
+            r[j] = ld(kcur + KM_RING);
+            if (kcur < count) {
+                if (MODE == 0) km_accumulate4<ABL>(c, v, run);
+                else {
+                    const float xa[4] = {v.x, v.y, v.z, v.w};
+                    km_emit<4, LT>(c, xa, 4 * (step_of(kcur) * KM_THREADS + threadIdx.x), labels_out, quant_out, dist_out, hist_s, hr);
                 }
             }
         }
@@ -1717,6 +1725,7 @@ extern "C" int nnc_debug_clock(int blocks, int iters, float *out_dev, void *stre
 }
 
 static int g_ablation = 0;
+static int g_deal = []() { const char *e = getenv("NNC_KM_DEAL"); return e ? atoi(e) : 1; }(); // tuning knob: 0 = contiguous ranges only
 extern "C" int nnc_debug_set_ablation(int a) { g_ablation = a; return NNC_OK; }
 
 static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream, int which = 0)
@@ -1737,6 +1746,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
     else if (vec && g_ablation == 2) KM_LAUNCH_ACC(true, uint8_t, 2);
     else if (vec && g_ablation == 3) KM_LAUNCH_ACC(true, uint8_t, 3);
+    else if (vec && g_deal && (grid & 1) == 0 && (p->n / (4 * KM_THREADS)) >= 4 * (int64_t)grid) KM_LAUNCH_ACC(true, uint8_t, 0, true);
     else if (vec) KM_LAUNCH_ACC(true, uint8_t);
     else KM_LAUNCH_ACC(false, uint8_t);
 #undef KM_LAUNCH_ACC
@@ -1752,6 +1762,7 @@ static int km_set_lds_attr()
     const int maxlds = 160 * 1024;
 #define SETATTR(fn) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds))
     SETATTR((k_assign<0, true, uint8_t>));
+    SETATTR((k_assign<0, true, uint8_t, 0, true>));
     SETATTR((k_assign<0, true, uint8_t, 1>));
     SETATTR((k_assign<0, true, uint8_t, 2>));
     SETATTR((k_assign<0, true, uint8_t, 3>));
