@@ -117,23 +117,22 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_signs(const float *__re
 
 static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-static hipError_t pruned_sizes(int64_t n_neg, int64_t n_pos, size_t *sort_bytes)
+static hipError_t pruned_sizes(int64_t n_nz, size_t *sort_bytes)
 {
-    size_t sa = 0, sb = 0;
+    size_t sa = 0;
     hipError_t e;
-    if (n_neg > 0 && (e = rocprim::radix_sort_keys(nullptr, sa, (const float *)nullptr, (float *)nullptr, (size_t)n_neg)) != hipSuccess) return e;
-    if (n_pos > 0 && (e = rocprim::radix_sort_keys(nullptr, sb, (const float *)nullptr, (float *)nullptr, (size_t)n_pos)) != hipSuccess) return e;
-    *sort_bytes = sa > sb ? sa : sb;
+    if (n_nz > 0 && (e = rocprim::radix_sort_keys(nullptr, sa, (const float *)nullptr, (float *)nullptr, (size_t)n_nz)) != hipSuccess) return e;
+    *sort_bytes = sa;
     return hipSuccess;
 }
 
 extern "C" size_t nnc_sort_pruned_workspace_bytes(int64_t n, int64_t n_neg, int64_t n_zero)
 {
     if (n <= 0 || n_neg < 0 || n_zero < 0 || n_neg + n_zero > n) return 0;
-    const int64_t n_pos = n - n_neg - n_zero;
+    const int64_t n_nz = n - n_zero;
     size_t sb = 0;
-    if (pruned_sizes(n_neg, n_pos, &sb) != hipSuccess) return 0;
-    return al256((size_t)(n_neg + n_pos) * 4 + 16) + al256(sizeof(unsigned long long)) + al256(sb) + 256;
+    if (pruned_sizes(n_nz, &sb) != hipSuccess) return 0;
+    return 2 * al256((size_t)n_nz * 4 + 16) + al256(sizeof(unsigned long long)) + al256(sb) + 256;
 }
 
 extern "C" int nnc_sort_pruned_f32(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float *sorted_out, void *ws,
@@ -142,16 +141,15 @@ extern "C" int nnc_sort_pruned_f32(const float *x, int64_t n, int64_t n_neg, int
     if (n < 0 || n_neg < 0 || n_zero < 0 || n_neg + n_zero > n || n >= ((int64_t)1 << 32) || (n > 0 && (!x || !sorted_out)))
         return nnc_set_error_(NNC_EINVAL, "nnc_sort_pruned_f32: bad argument");
     if (n == 0) return NNC_OK;
-    const int64_t n_pos = n - n_neg - n_zero;
+    const int64_t n_pos = n - n_neg - n_zero, n_nz = n_neg + n_pos;
     size_t sb = 0;
-    hipError_t e = pruned_sizes(n_neg, n_pos, &sb);
+    hipError_t e = pruned_sizes(n_nz, &sb);
     if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     if (!ws || ws_bytes < nnc_sort_pruned_workspace_bytes(n, n_neg, n_zero)) return nnc_set_error_(NNC_ENOSPACE, "nnc_sort_pruned_f32: workspace too small");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char *b = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
-    float *t_neg = reinterpret_cast<float *>(b);
-    float *t_pos = t_neg + n_neg;
-    b += al256((size_t)(n_neg + n_pos) * 4 + 16);
+    float *t_all = reinterpret_cast<float *>(b);    b += al256((size_t)n_nz * 4 + 16); // the non-zeros: negatives, then positives, each in any order
+    float *t_sorted = reinterpret_cast<float *>(b); b += al256((size_t)n_nz * 4 + 16);
     unsigned long long *counter = reinterpret_cast<unsigned long long *>(b); b += al256(sizeof(unsigned long long));
     void *stemp = b;
     e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
@@ -159,23 +157,22 @@ extern "C" int nnc_sort_pruned_f32(const float *x, int64_t n, int64_t n_neg, int
     {
         const long long tiles = (n / 4 + 4 * SPLIT_THREADS - 1) / (4 * SPLIT_THREADS);
         int grid = (int)std::min<long long>(std::max<long long>(tiles, 1), 512);
-        hipLaunchKernelGGL(k_split_signs, dim3(grid), dim3(SPLIT_THREADS), 0, s, x, (long long)n, t_neg, t_pos, counter, (long long)n_neg, (long long)n_pos);
+        hipLaunchKernelGGL(k_split_signs, dim3(grid), dim3(SPLIT_THREADS), 0, s, x, (long long)n, t_all, t_all + n_neg, counter, (long long)n_neg, (long long)n_pos);
         e = hipGetLastError();
         if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     }
-    if (n_neg > 0) {
+    // one sort of all the non-zeros (a radix sort of 8 M keys is well under twice the cost of one of 4 M), then the two
+    // halves go to their places either side of the zeros
+    if (n_nz > 0) {
         size_t need = sb;
-        e = rocprim::radix_sort_keys(stemp, need, (const float *)t_neg, sorted_out, (size_t)n_neg, 0, 32, s);
+        e = rocprim::radix_sort_keys(stemp, need, (const float *)t_all, t_sorted, (size_t)n_nz, 0, 32, s);
         if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     }
-    if (n_zero > 0) {
-        e = hipMemsetAsync(sorted_out + n_neg, 0, (size_t)n_zero * 4, s);
-        if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
-    }
-    if (n_pos > 0) {
-        size_t need = sb;
-        e = rocprim::radix_sort_keys(stemp, need, (const float *)t_pos, sorted_out + n_neg + n_zero, (size_t)n_pos, 0, 32, s);
-        if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
-    }
+    if (n_neg > 0 && (e = hipMemcpyAsync(sorted_out, t_sorted, (size_t)n_neg * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+        return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    if (n_zero > 0 && (e = hipMemsetAsync(sorted_out + n_neg, 0, (size_t)n_zero * 4, s)) != hipSuccess)
+        return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    if (n_pos > 0 && (e = hipMemcpyAsync(sorted_out + n_neg + n_zero, t_sorted + n_neg, (size_t)n_pos * 4, hipMemcpyDeviceToDevice, s)) != hipSuccess)
+        return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     return NNC_OK;
 }
