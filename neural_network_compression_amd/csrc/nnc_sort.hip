@@ -40,8 +40,8 @@ extern "C" int nnc_sort_f32(const float *x, int64_t n, float *sorted_out, void *
 
 // --------------------------------------------------------------------------------------
 // The same for a PRUNED vector: most weights are exact zeros, which need no sorting.  One
-// three-way partition (negatives / positives / zeros dropped), two radix sorts of the non-zero
-// parts straight into their places, zeros filled in between.  The counts come from
+// three-way split (negatives / positives / zeros dropped), one radix sort of the non-zeros, the
+// two halves copied to their places with the zeros filled in between.  The counts come from
 // nnc_minmax_signs_f32 (the fit set-up reads them together with min / max).  -0.0 counts as a
 // zero and comes back as +0.0: equal as a value, which is all the iterations look at.
 // --------------------------------------------------------------------------------------
