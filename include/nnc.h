@@ -195,6 +195,10 @@ int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, void *stream)
  * aligned, sizeof(nnc_kmeans_status) + 8 bytes) and then `ticket` into the 8 bytes behind it;
  * the host polls that word until it reads its ticket, then reads the status. */
 int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t ticket, void *stream);
+/* nnc_kmeans_iterate with the look-in attached to the last launch of the batch (no launch of its
+ * own): status block and ticket are written to host_mapped as by nnc_kmeans_status_publish. */
+int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params *p, int32_t iters, void *host_mapped,
+                               uint64_t ticket, void *stream);
 int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream);
 /* counts_dev[j] (int64, k entries) = number of weights of x whose nearest centre is j, for the
  * current centres (which = 0) or the previous ones (which = 1): the index histogram the Huffman

@@ -1547,9 +1547,17 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
 // cell g -> candidate range [first p with gc[p] >= g, last p with hc[p] <= g] (both monotone in g);
 // one cell per thread.  The first and last cells are open-ended: everything below lo / above hi
 // is clamped into them.
-__global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws)
+__global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc_kmeans_status *host_st,
+                                                      unsigned long long *host_ticket, unsigned long long ticket)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX];
+    // the last launch of a batch may carry the host's look-in (nnc_kmeans_iterate_publish): the state is final once
+    // k_finalize is through, so the status block and the ticket go out here, without a launch of their own
+    if (host_st && blockIdx.x == 0 && threadIdx.x == 0) {
+        *host_st = ws->st;
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
+    }
     if (!ws->cells_pending) return;
     const int G = 1 << ws->glog2;
     const int g = blockIdx.x * KM_THREADS + threadIdx.x;
@@ -1579,12 +1587,15 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws)
     tab->cell[g] = (uint16_t)(field | (c << KM_P_BITS));
 }
 
-static int km_launch_finalize(KmWs *w, int mode, int resume, void *stream)
+static int km_launch_finalize(KmWs *w, int mode, int resume, void *stream, void *host_mapped = nullptr, uint64_t ticket = 0)
 {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, mode, resume);
     LAUNCHCHK("k_finalize");
     if (mode != FIN_PACK_ONLY) {
-        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w);
+        unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
+        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w,
+                           reinterpret_cast<nnc_kmeans_status *>(hb),
+                           reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr), (unsigned long long)ticket);
         LAUNCHCHK("k_cells");
     }
     return NNC_OK;
@@ -1847,6 +1858,26 @@ extern "C" int nnc_kmeans_label_counts(const float *x, void *ws, const nnc_kmean
     if ((rc = km_launch_accumulate(x, w, &p, stream, 2 | (which & 1)))) return rc;
     hipLaunchKernelGGL(k_counts_from_shards, dim3(1), dim3(KM_THREADS), 0, S(stream), w, which, reinterpret_cast<long long *>(counts_dev));
     LAUNCHCHK("k_counts_from_shards");
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped,
+                                          uint64_t ticket, void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_iterate_publish");
+    if (rc) return rc;
+    const nnc_kmeans_params p = *pp;
+    if (p.n > 0 && !x) return fail(NNC_EINVAL, "nnc_kmeans_iterate_publish: null x");
+    if (p.n != p.n_total) return fail(NNC_EINVAL, "nnc_kmeans_iterate_publish: sharded vector (n != n_total) needs accumulate / all-reduce / finalize");
+    if (iters < 1 || !host_mapped || (reinterpret_cast<uintptr_t>(host_mapped) & 7) != 0)
+        return fail(NNC_EINVAL, "nnc_kmeans_iterate_publish: iters < 1, or null / unaligned host pointer");
+    if ((rc = km_set_lds_attr())) return rc;
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    for (int i = 0; i < iters; i++) {
+        if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
+        const bool last = i == iters - 1;
+        if ((rc = km_launch_finalize(w, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
+    }
     return NNC_OK;
 }
 

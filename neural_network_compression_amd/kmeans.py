@@ -238,6 +238,16 @@ class DeviceKMeans:
         """The device state after everything enqueued so far."""
         return self.wait(self.publish())
 
+    def iterate_and_look(self, iters: int) -> nat.KMeansStatus:
+        """`iters` iterations and the state behind them.  On one GPU the look-in rides on the batch's last launch."""
+        if self.group is not None:
+            self.iterate(iters)
+            return self.status()
+        self._ticket += 1
+        nat.check(self.L.nnc_kmeans_iterate_publish(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters),
+                                                    self._slot_addr[self._ticket & 1], self._ticket, self.stream))
+        return self.wait(self._ticket)
+
     def iterate(self, iters: int):
         """Enqueue `iters` Lloyd iterations (no host sync)."""
         if self.group is None:
@@ -412,8 +422,7 @@ class DeviceKMeans:
         batch = 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
         while True:
-            self.iterate(batch)
-            st = self.status()
+            st = self.iterate_and_look(batch)
             if st.done:
                 break
             if st.paused:
