@@ -93,8 +93,9 @@ def prune_(x: torch.Tensor, q: float, std_smooth: bool = True):
     L = nat.load()
     n = x.numel()
     mask = torch.empty(n, dtype=torch.uint8, device=x.device)
-    stats = torch.zeros(2, dtype=torch.float32, device=x.device)
-    nz = torch.zeros(1, dtype=torch.int64, device=x.device)
+    # (the library writes both: stats = {sigma, threshold} with std_smooth, {-, threshold} without; the count is zeroed there)
+    stats = torch.empty(2, dtype=torch.float32, device=x.device) if std_smooth else torch.zeros(2, dtype=torch.float32, device=x.device)
+    nz = torch.empty(1, dtype=torch.int64, device=x.device)
     ws_bytes = L.nnc_prune_workspace_bytes(n)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     nat.check(L.nnc_prune_f32(_ptr(x), n, float(np.float32(q)), 1 if std_smooth else 0, _ptr(mask), _ptr(stats),
@@ -109,7 +110,7 @@ def threshold_mask_(x: torch.Tensor, thr_dev: torch.Tensor):
     L = nat.load()
     n = x.numel()
     mask = torch.empty(n, dtype=torch.uint8, device=x.device)
-    nz = torch.zeros(1, dtype=torch.int64, device=x.device)
+    nz = torch.empty(1, dtype=torch.int64, device=x.device)   # zeroed by the library
     nat.check(L.nnc_threshold_mask_f32(_ptr(x), n, _ptr(thr_dev), _ptr(mask), _ptr(nz), _stream(x)))
     return mask.view(x.shape), nz
 
@@ -135,7 +136,7 @@ def minmax(x: torch.Tensor, skip_zeros: bool = False):
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     L = nat.load()
     out = torch.empty(2, dtype=torch.float32, device=x.device)
-    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+    cnt = torch.empty(1, dtype=torch.int64, device=x.device)   # written by the final reduction
     ws_bytes = L.nnc_minmax_workspace_bytes(x.numel())
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     nat.check(L.nnc_minmax_f32(_ptr(x), x.numel(), 1 if skip_zeros else 0, _ptr(out), _ptr(cnt), _ptr(ws), ws_bytes, _stream(x)))
