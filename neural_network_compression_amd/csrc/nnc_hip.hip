@@ -2273,6 +2273,72 @@ __global__ __launch_bounds__(256) void k_reloc_fill(const float *__restrict__ xs
     if (blockIdx.x == 0 && threadIdx.x < 4 && total + threadIdx.x < cap) cand_x[total + threadIdx.x] = 0.0f;
 }
 
+// Candidates AND their squared distances in one launch (what k_reloc_fill + k_assign<labels> on the candidate array
+// give, without the second launch): every workgroup stages the search tables in LDS as the streaming kernel does, then
+// its waves take windows in turn; the label is the exact float32 arg-min (km_resolve), the distance (x~ - c)^2.
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restrict__ xs, const KmWin *__restrict__ win,
+                                                           const int *__restrict__ meta, float *__restrict__ cand_x,
+                                                           float *__restrict__ cand_d, long long cap, const KmWs *__restrict__ ws)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (meta[2]) {
+        if (blockIdx.x == 0 && threadIdx.x < 4 && threadIdx.x < cap) { cand_x[threadIdx.x] = 0.0f; cand_d[threadIdx.x] = 0.0f; }
+        return;
+    }
+    const int k = ws->p.k, glog2 = ws->glog2;
+    const int G = 1 << glog2, kp = (k + 7) & ~7;
+    const KmTab *__restrict__ tab = &ws->tab[ws->cur];
+    const int kt = tab->ku;
+    uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
+    float4 *pair_s = reinterpret_cast<float4 *>(smem + ((size_t)2 << glog2));
+    float *cval_s = reinterpret_cast<float *>(smem + ((size_t)2 << glog2) + (size_t)kp * 16);
+    uint16_t *orig_s = reinterpret_cast<uint16_t *>(smem + ((size_t)2 << glog2) + (size_t)kp * 20);
+    const size_t off = (((size_t)2 << glog2) + (size_t)kp * 22 + 15) & ~(size_t)15;
+    unsigned *ovf_s = reinterpret_cast<unsigned *>(smem + off);
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(tab->cell);
+        uint4 *dst = reinterpret_cast<uint4 *>(cell_s);
+        for (int i = threadIdx.x; i < (G >> 3); i += KM_THREADS) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kt; i += KM_THREADS) {
+            const float2 a = tab->cand[i];
+            const float2 b = (i + 1 < kt) ? tab->cand[i + 1] : a;
+            pair_s[i] = make_float4(a.x, a.y, b.x, b.y);
+            cval_s[i] = a.x;
+            orig_s[i] = tab->orig[i];
+        }
+        const int novf = min(tab->n_ovf, KM_OVF_MAX);
+        for (int i = threadIdx.x; i < novf; i += KM_THREADS) ovf_s[i] = tab->ovf[i];
+    }
+    __syncthreads();
+    KmCtx c;
+    c.cell_s = cell_s; c.pair_s = pair_s; c.cval_s = cval_s; c.orig_s = orig_s; c.ovf_s = ovf_s; c.sum_s = nullptr; c.cnt_s = nullptr;
+    c.mean = ws->p.x_mean; c.lo = ws->p.lo; c.inv = ws->inv;
+    c.Sft = ws->p.fix_shift; c.gmax = G - 1; c.k = kt; c.rlog2 = 0; c.rep = 0;
+    // candidate i lives in the window whose offset range holds i (a tail window may be thousands of values long, so
+    // the work is split by candidate, not by window): window offsets in LDS, one binary search per candidate
+    const int nwin = meta[1];
+    const long long total = meta[0];
+    int *woff_s = reinterpret_cast<int *>(smem + off + KM_OVF_MAX * 4); // behind the side list: (NNC_KMAX + 2) ints
+    for (int j = threadIdx.x; j < nwin; j += KM_THREADS) woff_s[j] = win[j].off;
+    __syncthreads();
+    for (long long i = (long long)blockIdx.x * KM_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * KM_THREADS) {
+        int l = 0, h = nwin - 1; // last window with off <= i (empty windows share an offset with their successor: any of them will do
+        while (l < h) { const int m = (l + h + 1) >> 1; if (woff_s[m] <= (int)i) l = m; else h = m - 1; }
+        // ... as long as it is not empty: step back over empty ones to the window that really holds i)
+        KmWin w = win[l];
+        while (w.len == 0 || (int)i - w.off >= w.len) { l--; w = win[l]; }
+        const float xv[1] = {xs[w.start + ((int)i - w.off)]};
+        float xc[1];
+        int p[1];
+        km_resolve<1>(c, xv, xc, p);
+        const float dd = xc[0] - cval_s[p[0]];
+        cand_x[i] = xv[0];
+        cand_d[i] = dd * dd;
+    }
+    // up to three values after the last candidate are read as part of a 16-byte load by the selection
+    if (blockIdx.x == 0 && threadIdx.x < 4 && total + threadIdx.x < cap) { cand_x[total + threadIdx.x] = 0.0f; cand_d[total + threadIdx.x] = 0.0f; }
+}
+
 // One workgroup: the n_empty largest keys among the candidates (histogram cut on the distance
 // bits, refined while crowded, exact ranking of the survivors), the proof that nothing outside
 // the windows can beat them, and -- if it holds -- the relocation itself.
@@ -2503,6 +2569,29 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
 #undef RSTAMP
 }
 
+static bool g_reloc_dist_attr = false;
+// windows, candidates and their distances (two launches)
+static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window, float *cand_x,
+                                 float *cand_d, int64_t cap, void *win_dev, int32_t *meta_dev, void *stream)
+{
+    int glog2, rlog2;
+    km_defaults(p, &glog2, &rlog2);
+    const size_t lds = km_lds_bytes(p->k, glog2, rlog2, false) + (NNC_KMAX + 2) * sizeof(int);
+    if (!g_reloc_dist_attr) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        g_reloc_dist_attr = true;
+    }
+    hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
+                       reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
+                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev));
+    LAUNCHCHK("k_reloc_windows");
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(64, (2 * (int64_t)window * (p->k + 1) + 4 * KM_THREADS - 1) / (4 * KM_THREADS))); // a few candidates per thread
+    hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
+                       reinterpret_cast<const int *>(meta_dev), cand_x, cand_d, (long long)cap, reinterpret_cast<const KmWs *>(ws));
+    LAUNCHCHK("k_reloc_dist");
+    return NNC_OK;
+}
+
 extern "C" int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window,
                                            float *cand_x_dev, int64_t cap, void *win_dev, int32_t *meta_dev, void *stream)
 {
@@ -2578,11 +2667,7 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
     void *win = b; b += reloc_align(16 * (size_t)(p->k + 2));
     int32_t *meta = reinterpret_cast<int32_t *>(b); b += reloc_align(16);
     int64_t *keys = reinterpret_cast<int64_t *>(b);
-    if ((rc = nnc_kmeans_reloc_candidates(x_sorted, ws, p, window, cand_x, cap, win, meta, stream))) return rc;
-    nnc_kmeans_params pc = *p;
-    pc.n = cap;
-    pc.n_total = std::max<int64_t>(cap, p->n_total);
-    if ((rc = km_assign(cand_x, ws, &pc, 0, nullptr, 1, nullptr, cand_d, nullptr, meta, stream))) return rc; // meta[0] = n_cand
+    if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, stream))) return rc;
     if ((rc = nnc_kmeans_relocate_checked(ws, cand_x, cand_d, win, meta, n_empty, keys, stream))) return rc;
     return nnc_kmeans_finalize(ws, 1, stream);
 }
@@ -2607,11 +2692,7 @@ extern "C" int nnc_kmeans_reloc_select_local(const float *x_sorted, void *ws, co
     float *cand_d = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
     void *win = b; b += reloc_align(16 * (size_t)(p->k + 2));
     int32_t *meta = reinterpret_cast<int32_t *>(b);
-    if ((rc = nnc_kmeans_reloc_candidates(x_sorted, ws, p, window, cand_x, cap, win, meta, stream))) return rc;
-    nnc_kmeans_params pc = *p;
-    pc.n = cap;
-    pc.n_total = std::max<int64_t>(cap, p->n_total);
-    if ((rc = km_assign(cand_x, ws, &pc, 0, nullptr, 1, nullptr, cand_d, nullptr, meta, stream))) return rc; // meta[0] = n_cand
+    if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, stream))) return rc;
     hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
                        reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
                        reinterpret_cast<long long *>(keys_out_dev), 0);
