@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Randomised parity stress: fits on sorted-size vectors with duplicate / crowded / out-of-range initial centres,
+pruned and unpruned, against the oracle (mode B), bit for bit.  Not part of the test suite (minutes of CPU)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from neural_network_compression_amd import kmeans, synth
+from oracle import oracle as orc
+
+rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = 0
+t0 = time.time()
+for case in range(ncases):
+    n = int(rng.choice([66_000, 70_001, 131_072, 200_003, 300_000, 450_000]))
+    x = synth.weights((n,), 9000 + case, scale=float(rng.choice([0.05, 0.5, 3e-4])))
+    kind = rng.randint(0, 5)
+    if kind in (0, 1):
+        x[np.abs(x) < np.float32(rng.uniform(0.2, 1.5)) * x.std()] = 0
+    if kind == 2:
+        x = (np.round(x / x.std() * rng.randint(3, 40)) * x.std() / 17).astype(np.float32)   # few distinct values
+    k = int(rng.choice([4, 16, 33, 64, 100, 257]))
+    style = rng.randint(0, 5)
+    lo, hi = float(x.min()), float(x.max())
+    if style == 0:
+        init = np.linspace(lo, hi, k)
+    elif style == 1:
+        init = np.repeat(np.quantile(x.astype(np.float64), np.linspace(0.02, 0.98, max(2, k // 4))), 4)[:k]
+    elif style == 2:
+        init = x[rng.randint(0, n, size=k)]
+    elif style == 3:
+        init = np.linspace(lo * 1.7, hi * 1.7, k)
+    else:
+        init = np.concatenate([np.full(k // 2, np.median(x)), rng.uniform(lo, hi, k - k // 2)])
+    init = np.asarray(init, dtype=np.float32)
+    if init.size < k:
+        init = np.concatenate([init, np.full(k - init.size, init[-1], dtype=np.float32)])
+    ob = orc.kmeans_lloyd(x, init, accum="B")
+    km = kmeans.DeviceKMeans(torch.from_numpy(x).cuda(), init)
+    model, vals = km.fit()
+    ok = (model.n_iter_ == ob.n_iter_ and np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
+          and np.array_equal(model.labels_, ob.labels_)
+          and np.array_equal(model.counts_device_.cpu().numpy(), np.bincount(ob.labels_, minlength=k)))
+    print(f"case {case}: n={n} k={k} kind={kind} init={style} n_iter={model.n_iter_}/{ob.n_iter_} reloc={model.n_relocations_} "
+          f"windowed={model.n_reloc_windowed_} stop={model.stop_reason_} {'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += (not ok)
+print(f"{ncases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
