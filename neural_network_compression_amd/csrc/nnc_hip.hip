@@ -2194,8 +2194,10 @@ __device__ __forceinline__ void block_scan2(long long &a0, long long &a1, long l
 
 // one workgroup: the window table.  meta = {n_cand, n_windows, bad, window}
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, const KmWs *__restrict__ ws,
-                                                              int W, long long cap, KmWin *__restrict__ win, int *__restrict__ meta)
+                                                              int W, long long cap, KmWin *__restrict__ win, int *__restrict__ meta,
+                                                              unsigned *__restrict__ hist0 = nullptr)
 {
+    if (hist0) for (int i = threadIdx.x; i < 4096; i += KM_THREADS) hist0[i] = 0u; // k_reloc_dist adds to it
     __shared__ long long bnd[2 * KM_THREADS + 2];
     __shared__ long long wst[2 * KM_THREADS], wen[2 * KM_THREADS];
     __shared__ long long wave_tot[KM_THREADS / 64];
@@ -2278,9 +2280,12 @@ __global__ __launch_bounds__(256) void k_reloc_fill(const float *__restrict__ xs
 // its waves take windows in turn; the label is the exact float32 arg-min (km_resolve), the distance (x~ - c)^2.
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restrict__ xs, const KmWin *__restrict__ win,
                                                            const int *__restrict__ meta, float *__restrict__ cand_x,
-                                                           float *__restrict__ cand_d, long long cap, const KmWs *__restrict__ ws)
+                                                           float *__restrict__ cand_d, long long cap, const KmWs *__restrict__ ws,
+                                                           unsigned *__restrict__ hist0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned h0_s[4096]; // first level of the selection's histogram (top 12 bits of the distance), for free here
+    for (int i = threadIdx.x; i < 4096; i += KM_THREADS) h0_s[i] = 0u;
     if (meta[2]) {
         if (blockIdx.x == 0 && threadIdx.x < 4 && threadIdx.x < cap) { cand_x[threadIdx.x] = 0.0f; cand_d[threadIdx.x] = 0.0f; }
         return;
@@ -2332,9 +2337,14 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restri
         int p[1];
         km_resolve<1>(c, xv, xc, p);
         const float dd = xc[0] - cval_s[p[0]];
+        const float dv = dd * dd;
         cand_x[i] = xv[0];
-        cand_d[i] = dd * dd;
+        cand_d[i] = dv;
+        atomicAdd(&h0_s[(__float_as_uint(dv) >> 19) & 4095u], 1u);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096; i += KM_THREADS)
+        if (h0_s[i]) atomicAdd(&hist0[i], h0_s[i]);
     // up to three values after the last candidate are read as part of a 16-byte load by the selection
     if (blockIdx.x == 0 && threadIdx.x < 4 && total + threadIdx.x < cap) { cand_x[total + threadIdx.x] = 0.0f; cand_d[total + threadIdx.x] = 0.0f; }
 }
@@ -2345,7 +2355,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restri
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
                                                              const float *__restrict__ cand_d, const KmWin *__restrict__ win,
                                                              const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out,
-                                                             int do_relocate)
+                                                             int do_relocate, const unsigned *__restrict__ hist0 = nullptr)
 {
     __shared__ __align__(8) unsigned hist[4096];
     __shared__ unsigned long long surv[KM_SURV_MAX];
@@ -2374,12 +2384,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     for (int lvl = 0; lvl < 3; lvl++) {
         const int shift = shifts[lvl], width = widths[lvl];
         const unsigned mask = (1u << width) - 1u;
-        for (int i = tid; i < 4096; i += KM_THREADS) hist[i] = 0;
+        for (int i = tid; i < 4096; i += KM_THREADS) hist[i] = (lvl == 0 && hist0) ? hist0[i] : 0u; // the first level may come with the candidates
         if (tid == 0) { s_cut = 0; s_above = above; s_ge = total_ge; }
         __syncthreads();
         const unsigned NOBIN = 0xFFFFu;
         auto bin_of = [&](unsigned u) -> unsigned { return (pshift < 0 || (u >> pshift) == prefix) ? ((u >> shift) & mask) : NOBIN; };
-        for (int v0 = 0; v0 < nvec; v0 += 8 * KM_THREADS) { // wave-uniform trip count; eight loads in flight per thread
+        for (int v0 = 0; v0 < ((lvl == 0 && hist0) ? 0 : nvec); v0 += 8 * KM_THREADS) { // wave-uniform trip count; eight loads in flight per thread
             uint4 qv[8];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -2408,7 +2418,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
                 }
             }
         }
-        for (int i = (nvec << 2) + tid; i < n_cand; i += KM_THREADS) {
+        for (int i = ((lvl == 0 && hist0) ? n_cand : (nvec << 2)) + tid; i < n_cand; i += KM_THREADS) {
             const unsigned bn = bin_of(__float_as_uint(cand_d[i]));
             if (bn != NOBIN) atomicAdd(&hist[bn], 1u);
         }
@@ -2572,22 +2582,23 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
 static bool g_reloc_dist_attr = false;
 // windows, candidates and their distances (two launches)
 static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window, float *cand_x,
-                                 float *cand_d, int64_t cap, void *win_dev, int32_t *meta_dev, void *stream)
+                                 float *cand_d, int64_t cap, void *win_dev, int32_t *meta_dev, unsigned *hist0, void *stream)
 {
     int glog2, rlog2;
     km_defaults(p, &glog2, &rlog2);
     const size_t lds = km_lds_bytes(p->k, glog2, rlog2, false) + (NNC_KMAX + 2) * sizeof(int);
+    if (lds > 128 * 1024) return fail(NNC_EINVAL, "relocation: search tables too large for the candidate kernel");
     if (!g_reloc_dist_attr) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); // + 16 KB static
         g_reloc_dist_attr = true;
     }
     hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
                        reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
-                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev));
+                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev), hist0);
     LAUNCHCHK("k_reloc_windows");
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(64, (2 * (int64_t)window * (p->k + 1) + 4 * KM_THREADS - 1) / (4 * KM_THREADS))); // a few candidates per thread
     hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
-                       reinterpret_cast<const int *>(meta_dev), cand_x, cand_d, (long long)cap, reinterpret_cast<const KmWs *>(ws));
+                       reinterpret_cast<const int *>(meta_dev), cand_x, cand_d, (long long)cap, reinterpret_cast<const KmWs *>(ws), hist0);
     LAUNCHCHK("k_reloc_dist");
     return NNC_OK;
 }
@@ -2647,7 +2658,7 @@ extern "C" size_t nnc_kmeans_reloc_scratch_bytes(int32_t k, int32_t window)
 {
     if (k < 1 || window < 1) return 0;
     const size_t cap = (size_t)reloc_cap(k, window);
-    return 2 * reloc_align(cap * 4) + reloc_align(16 * (size_t)(k + 2)) + reloc_align(16) + reloc_align(8 * (size_t)NNC_KMAX);
+    return 2 * reloc_align(cap * 4) + reloc_align(16 * (size_t)(k + 2)) + reloc_align(16) + reloc_align(8 * (size_t)NNC_KMAX) + reloc_align(4096 * 4);
 }
 
 extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
@@ -2666,9 +2677,13 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
     float *cand_d = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
     void *win = b; b += reloc_align(16 * (size_t)(p->k + 2));
     int32_t *meta = reinterpret_cast<int32_t *>(b); b += reloc_align(16);
-    int64_t *keys = reinterpret_cast<int64_t *>(b);
-    if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, stream))) return rc;
-    if ((rc = nnc_kmeans_relocate_checked(ws, cand_x, cand_d, win, meta, n_empty, keys, stream))) return rc;
+    int64_t *keys = reinterpret_cast<int64_t *>(b); b += reloc_align(8 * (size_t)NNC_KMAX);
+    unsigned *hist0 = reinterpret_cast<unsigned *>(b);
+    if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, hist0, stream))) return rc;
+    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
+                       reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
+                       reinterpret_cast<long long *>(keys), 1, hist0);
+    LAUNCHCHK("k_reloc_select");
     return nnc_kmeans_finalize(ws, 1, stream);
 }
 
@@ -2691,11 +2706,12 @@ extern "C" int nnc_kmeans_reloc_select_local(const float *x_sorted, void *ws, co
     float *cand_x = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
     float *cand_d = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
     void *win = b; b += reloc_align(16 * (size_t)(p->k + 2));
-    int32_t *meta = reinterpret_cast<int32_t *>(b);
-    if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, stream))) return rc;
+    int32_t *meta = reinterpret_cast<int32_t *>(b); b += reloc_align(16) + reloc_align(8 * (size_t)NNC_KMAX);
+    unsigned *hist0 = reinterpret_cast<unsigned *>(b);
+    if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, hist0, stream))) return rc;
     hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
                        reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
-                       reinterpret_cast<long long *>(keys_out_dev), 0);
+                       reinterpret_cast<long long *>(keys_out_dev), 0, hist0);
     LAUNCHCHK("k_reloc_select");
     return NNC_OK;
 }
