@@ -691,7 +691,8 @@ struct KmWs {
     int32_t reloc_fail; // the windowed farthest-sample selection could not prove its result: redo it the long way
     float inv;         // cells per unit: cell = (int)((x~ - lo) * inv)
     int32_t cells_pending; // k_finalize left new zones: k_cells has to rebuild tab[cur].cell
-    float pad1[2];
+    int32_t ku_cur;    // = tab[cur].ku, here so that k_cells learns it in its first round of loads
+    float pad1;
     float c[2][NNC_KMAX];        // centred centres in ORIGINAL index order; [cur] current, [cur^1] previous
     long long partials[2 * NNC_KMAX]; // sums then counts, original index order (all-reduced across ranks)
     long long partials_local[2 * NNC_KMAX]; // this rank's own sums/counts of the last accumulated iteration
@@ -1125,6 +1126,26 @@ template <typename F>
 __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 {
     const int tid = threadIdx.x, nthr = blockDim.x;
+    if (n <= LEAF) { // a single leaf: eight lanes of the first wave, no tree
+        if (tid < 8) {
+            float res = 0.0f;
+            if (n < 8) {
+                for (int i = 0; i < n; i++) res += elem(i);
+            } else {
+                float r = elem(tid);
+                const int lim = n - (n % 8);
+                for (int i = 8; i < lim; i += 8) r += elem(i + tid);
+                r = r + __shfl_xor(r, 1);
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                res = r;
+                for (int i = lim; i < n; i++) res += elem(i);
+            }
+            if (tid == 0) hp->val[1] = res;
+        }
+        __syncthreads();
+        return hp->val[1];
+    }
     for (int i = tid; i < 256; i += nthr) { hp->start[i] = 0; hp->len[i] = 0; hp->val[i] = 0.0f; }
     __syncthreads();
     if (tid == 0) { hp->start[1] = 0; hp->len[1] = n; }
@@ -1183,7 +1204,10 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 #define FIN_FROM_PARTIALS 2 // multi GPU / resume: partials already hold the global sums
 #define FIN_PACK_ONLY 3     // reduce shards -> partials, nothing else
 
-__global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, int mode, int resume)
+// NT threads: a fit with few centres runs it as a single wave (64) or four (256), for which the many barriers and
+// wave-to-wave hand-overs of the scans cost next to nothing; NT >= k is all it needs (k > 1024 takes two rounds of 1024).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume)
 {
     __shared__ long long sum_o[NNC_KMAX];
     __shared__ long long cnt_o[NNC_KMAX];
@@ -1197,29 +1221,34 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
     __shared__ float cu[NNC_KMAX];     // distinct sorted centre values
     __shared__ uint16_t sou[NNC_KMAX]; // their (lowest) original indices
-    __shared__ double wave_a[KM_THREADS / 64], wave_b[KM_THREADS / 64];
+    __shared__ double wave_a[NT / 64], wave_b[NT / 64];
 
     const int tid = threadIdx.x;
     unsigned long long *ftr = g_fin_trace;
 #define FSTAMP(i) do { if (ftr && tid == 0) ftr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     FSTAMP(0);
     if (tid == 0) ws->cells_pending = 0;
-    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && ws->st.done) return;
-    if (mode == FIN_FROM_SHARDS && ws->st.paused) return;
-    if (mode == FIN_PACK_ONLY && (ws->st.done | ws->st.paused)) {
+    // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
+    // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
+    const int st_done = ws->st.done, st_paused = ws->st.paused, st_iter = ws->st.iter, reloc_fail = ws->reloc_fail;
+    const int k = ws->p.k, Sft = ws->p.fix_shift, max_iter = ws->p.max_iter, glog2 = ws->glog2;
+    const float tol_v = ws->p.tol, p_lo = ws->p.lo, p_hi = ws->p.hi, inv_f = ws->inv;
+    const int ku0 = ws->tab[0].ku, ku1 = ws->tab[1].ku;
+    int cur = ws->cur;
+    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) return;
+    if (mode == FIN_FROM_SHARDS && st_paused) return;
+    if (mode == FIN_PACK_ONLY && (st_done | st_paused)) {
         // no new iteration was accumulated: hand the all-reduce this rank's own sums again,
         // so that reducing an idle iteration leaves `partials` unchanged
-        const int k2 = 2 * ws->p.k;
-        for (int i = tid; i < k2; i += KM_THREADS) ws->partials[i] = ws->partials_local[i];
+        const int k2 = 2 * k;
+        for (int i = tid; i < k2; i += NT) ws->partials[i] = ws->partials_local[i];
         return;
     }
-    if (mode == FIN_FROM_PARTIALS && ws->st.paused && !resume) return;
-    if (resume && ws->reloc_fail) { // unproven windowed selection: stay paused, tell the host
+    if (mode == FIN_FROM_PARTIALS && st_paused && !resume) return;
+    if (resume && reloc_fail) { // unproven windowed selection: stay paused, tell the host
         if (tid == 0) ws->st.paused = 2;
         return;
     }
-    const int k = ws->p.k;
-    int cur = ws->cur;
 
     // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept its
     // count (prev_counts); the host runs the full label comparison (strict convergence) only then.
@@ -1227,13 +1256,24 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     const bool track = (mode == FIN_FROM_SHARDS) || (mode == FIN_FROM_PARTIALS && !resume);
     long long pc[2] = {0, 0};
     if (track)
-        for (int j = tid, r = 0; j < k; j += KM_THREADS, r++) pc[r] = ws->prev_counts[j];
+        for (int j = tid, r = 0; j < k; j += NT, r++) pc[r] = ws->prev_counts[j];
+    // second (and last) round of loads: the previous centres and the order the E-step of this iteration used
+    float cold_r[2] = {0.0f, 0.0f};
+    int spa[2] = {0, 0}, spb[2] = {0, 0}; // k <= 1040 < 2 * NT
+    if (mode != FIN_INIT) {
+        const uint16_t *so_e = ws->tab[cur].perm;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int j = tid + r * NT;
+            if (j < k) { cold_r[r] = ws->c[cur][j]; spa[r] = so_e[j]; spb[r] = (j + 1 < k) ? so_e[j + 1] : 0; }
+        }
+    }
     if (mode == FIN_FROM_SHARDS || mode == FIN_PACK_ONLY) {
         const KmTab *tab = &ws->tab[cur];
-        const int ku_cur = tab->ku;
-        for (int j = tid; j < k; j += KM_THREADS) { sum_o[j] = 0; cnt_o[j] = 0; } // duplicates of a centre own nothing
+        const int ku_cur = cur ? ku1 : ku0;
+        for (int j = tid; j < k; j += NT) { sum_o[j] = 0; cnt_o[j] = 0; } // duplicates of a centre own nothing
         __syncthreads();
-        for (int p = tid; p < ku_cur; p += KM_THREADS) {
+        for (int p = tid; p < ku_cur; p += NT) {
             long long s = 0;
             unsigned long long c = 0;
             const int o = tab->orig[p];
@@ -1244,18 +1284,18 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             sum_o[o] = s; cnt_o[o] = (long long)c;
         }
         __syncthreads();
-        for (int j = tid; j < k; j += KM_THREADS) {
+        for (int j = tid; j < k; j += NT) {
             ws->partials[j] = sum_o[j]; ws->partials[k + j] = cnt_o[j];
             ws->partials_local[j] = sum_o[j]; ws->partials_local[k + j] = cnt_o[j];
         }
         if (mode == FIN_PACK_ONLY) return;
     } else if (mode == FIN_FROM_PARTIALS) {
-        for (int j = tid; j < k; j += KM_THREADS) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
+        for (int j = tid; j < k; j += NT) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
     __syncthreads();
     if (track) {
         int count_diff = 0;
-        for (int j = tid, r = 0; j < k; j += KM_THREADS, r++) {
+        for (int j = tid, r = 0; j < k; j += NT, r++) {
             const long long c = cnt_o[j];
             count_diff |= (pc[r] != c);
             ws->prev_counts[j] = c;
@@ -1268,7 +1308,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     if (mode != FIN_INIT) {
         // ---- empty clusters?  (one barrier-with-count)
         int my_empty = 0;
-        for (int j = tid; j < k; j += KM_THREADS) my_empty += (cnt_o[j] == 0);
+        for (int j = tid; j < k; j += NT) my_empty += (cnt_o[j] == 0);
         if (tid == 0) sh_key = 0ull;
         const int n_empty = __syncthreads_count(my_empty);
         if (n_empty > 0 && !resume) {
@@ -1280,17 +1320,16 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             return;
         }
         // ---- _average_centers
-        const int Sft = ws->p.fix_shift;
-        for (int j = tid; j < k; j += KM_THREADS)
+        for (int j = tid; j < k; j += NT)
             if (cnt_o[j] > 0) cnew[j] = (float)ldexp((double)sum_o[j] / (double)cnt_o[j], -Sft);
         __syncthreads();
         if (n_empty > 0) { // only after a relocation that bailed out (all samples on their centres)
             // first index of the largest count (key = count, then lowest index)
-            for (int j = tid; j < k; j += KM_THREADS)
+            for (int j = tid; j < k; j += NT)
                 atomicMax(&sh_key, ((unsigned long long)cnt_o[j] << 11) | (unsigned long long)(2047 - j));
             __syncthreads();
             const int amax = 2047 - (int)(sh_key & 2047ull);
-            for (int j = tid; j < k; j += KM_THREADS)
+            for (int j = tid; j < k; j += NT)
                 if (cnt_o[j] <= 0) {
                     // sklearn copies centers[argmax] as it stands: averaged if argmax < j, raw sum otherwise
                     cnew[j] = (amax < j) ? cnew[amax] : (float)ldexp((double)sum_o[amax], -Sft);
@@ -1299,9 +1338,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         }
         FSTAMP(2);
         // ---- _center_shift and the tolerance test
-        const float *cold = ws->c[cur];
-        for (int j = tid; j < k; j += KM_THREADS) {
-            float d = cnew[j] - cold[j];
+        for (int j = tid, r = 0; j < k; j += NT, r++) {
+            float d = cnew[j] - cold_r[r];
             float s2 = d * d;
             float sft = (float)sqrt((double)s2);
             sq[j] = sft * sft;
@@ -1309,19 +1347,19 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         __syncthreads();
         const float tot = block_pairwise_sum([&](int i) { return sq[i]; }, k, &heap);
         if (tid == 0) {
-            int iter = ws->st.iter + 1;
+            int iter = st_iter + 1;
             int done = 0;
-            if (tot <= ws->p.tol) done = 1;
-            else if (iter >= ws->p.max_iter) done = 2;
+            if (tot <= tol_v) done = 1;
+            else if (iter >= max_iter) done = 2;
             ws->st.iter = iter; ws->st.shift_tot = tot; ws->st.done = done;
             ws->st.paused = 0; ws->st.n_empty = 0;
             ws->cur = cur ^ 1;
         }
         cur ^= 1;
-        for (int j = tid; j < k; j += KM_THREADS) ws->c[cur][j] = cnew[j];
+        for (int j = tid; j < k; j += NT) ws->c[cur][j] = cnew[j];
         __syncthreads();
     } else {
-        for (int j = tid; j < k; j += KM_THREADS) cnew[j] = ws->c[cur][j];
+        for (int j = tid; j < k; j += NT) cnew[j] = ws->c[cur][j];
         __syncthreads();
     }
 
@@ -1331,14 +1369,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     // the centres move little per iteration: first try the previous permutation
     int still_sorted = 0;
     if (mode != FIN_INIT) {
-        const uint16_t *so_prev = ws->tab[cur ^ 1].perm; // the order the E-step of this iteration used
         int ok = 1;
-        for (int p = tid; p < k; p += KM_THREADS) {
-            const int a = so_prev[p];
+        for (int p = tid, r = 0; p < k; p += NT, r++) {
+            const int a = spa[r];
             so[p] = (uint16_t)a;
             cs[p] = cnew[a];
             if (p + 1 < k) {
-                const int b = so_prev[p + 1];
+                const int b = spb[r];
                 const float va = cnew[a], vb = cnew[b];
                 ok &= (va < vb) || (va == vb && a < b);
             }
@@ -1356,7 +1393,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
                 __syncthreads();
             }
             int ok2 = 1;
-            for (int p = tid; p + 1 < k; p += KM_THREADS) {
+            for (int p = tid; p + 1 < k; p += NT) {
                 const float va = cs[p], vb = cs[p + 1];
                 ok2 &= (va < vb) || (va == vb && so[p] < so[p + 1]);
             }
@@ -1368,9 +1405,9 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     if (!still_sorted) {
         // rank by counting; PARTS lanes share one element and split the comparisons
         int parts = 1;
-        while (parts < 64 && k * parts * 2 <= KM_THREADS) parts <<= 1;
+        while (parts < 64 && k * parts * 2 <= NT) parts <<= 1;
         const int per_part = (k + parts - 1) / parts;
-        for (int t = tid; t < ((k * parts + KM_THREADS - 1) / KM_THREADS) * KM_THREADS; t += KM_THREADS) {
+        for (int t = tid; t < ((k * parts + NT - 1) / NT) * NT; t += NT) {
             const int j = t / parts, part = t % parts;
             int rank = 0;
             float v = 0.0f;
@@ -1394,10 +1431,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     int ku = 0;
     {
         int *wave_i = reinterpret_cast<int *>(wave_a);
-        const int rounds_u = (k + KM_THREADS - 1) / KM_THREADS;
+        const int rounds_u = (k + NT - 1) / NT;
         int carry = 0;
         for (int rd = 0; rd < rounds_u; rd++) {
-            const int p = rd * KM_THREADS + tid;
+            const int p = rd * NT + tid;
             float v = 0.0f;
             int o = 0, first = 0;
             if (p < k) {
@@ -1410,7 +1447,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             if ((tid & 63) == 0) wave_i[tid >> 6] = __popcll(bal);
             __syncthreads();
             int pre = carry, tot = carry;
-            for (int w = 0; w < KM_THREADS / 64; w++) { const int wv = wave_i[w]; if (w < (tid >> 6)) pre += wv; tot += wv; }
+            for (int w = 0; w < NT / 64; w++) { const int wv = wave_i[w]; if (w < (tid >> 6)) pre += wv; tot += wv; }
             if (first) { cu[pre + before] = v; sou[pre + before] = (uint16_t)o; }
             carry = tot;
             __syncthreads();
@@ -1418,13 +1455,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
         ku = carry;
     }
     FSTAMP(10);
-    for (int p = tid; p < ku; p += KM_THREADS) {
+    for (int p = tid; p < ku; p += NT) {
         const float v = cu[p];
         cs[p] = v;
         tab->cand[p] = make_float2(v, v * v);
         tab->orig[p] = sou[p];
     }
-    if (tid == 0) { tab->ku = ku; ovf_n = 0; }
+    if (tid == 0) { tab->ku = ku; ws->ku_cur = ku; ovf_n = 0; }
     __syncthreads();
     FSTAMP(4);
     // ---- zone of every centre: the x-interval [left, right] on which it can be the float32 arg-min,
@@ -1434,20 +1471,19 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
     // monotone (prefix max / suffix min), so that the candidate range of a cell is
     // [first p with G_p >= g, last p with H_p <= g].
     const double U = 5.9604644775390625e-08; // 2^-24
-    const double xb = fmax(fabs((double)ws->p.lo), fabs((double)ws->p.hi));
-    const int glog2 = ws->glog2;
+    const double xb = fmax(fabs((double)p_lo), fabs((double)p_hi));
     const int G = 1 << glog2;
-    const double lo = (double)ws->p.lo;
-    const double inv = (double)ws->inv;
+    const double lo = (double)p_lo;
+    const double inv = (double)inv_f;
     const double ra = inv > 0.0 ? (1.0 - 4.0 * U) / inv * (1.0 - 4.0 * U) : 0.0;
     const double rb = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0;
     {
-        const int rounds = (ku + KM_THREADS - 1) / KM_THREADS;
+        const int rounds = (ku + NT - 1) / NT;
         int *wave_i = reinterpret_cast<int *>(wave_a);
         int carry_g = -2;
-        int gp_r[2], hp_r[2]; // ku <= 1040 < 2 * KM_THREADS
+        int gp_r[2], hp_r[2]; // ku <= 1040 < 2 * NT
         for (int rd = 0; rd < rounds; rd++) {
-            const int p = rd * KM_THREADS + tid;
+            const int p = rd * NT + tid;
             int gp = -2, hp_ = G + 1;
             if (p < ku) {
                 const double cp = (double)cs[p];
@@ -1491,54 +1527,44 @@ __global__ __launch_bounds__(KM_THREADS) void k_finalize(KmWs *__restrict__ ws, 
             gp_r[rd] = gp; hp_r[rd] = hp_;
         }
         FSTAMP(11);
-        // prefix max of G_p
-        for (int rd = 0; rd < rounds; rd++) {
-            const int p = rd * KM_THREADS + tid;
-            int a = gp_r[rd];
+        // prefix max of G_p and suffix min of H_p, side by side (one pair of barriers for both)
+        int *wave_g = reinterpret_cast<int *>(wave_a);
+        int *wave_h = reinterpret_cast<int *>(wave_b);
+        int carry_h = G + 1;
+        const int lane = tid & 63, myw = tid >> 6;
+        for (int it = 0; it < rounds; it++) {
+            const int rg = it, rh = rounds - 1 - it; // the prefix runs up the rounds, the suffix down
+            int a = rg ? gp_r[1] : gp_r[0];
+            int b = rh ? hp_r[1] : hp_r[0];
             for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(a, off);
-                if ((tid & 63) >= off) a = max(a, o);
+                const int oa = __shfl_up(a, off), ob = __shfl_down(b, off);
+                if (lane >= off) a = max(a, oa);
+                if (lane + off < 64) b = min(b, ob);
             }
-            if ((tid & 63) == 63) wave_i[tid >> 6] = a;
+            if (lane == 63) wave_g[myw] = a;
+            if (lane == 0) wave_h[myw] = b;
             __syncthreads();
-            int pre = carry_g, tot = carry_g;
-            for (int w = 0; w < KM_THREADS / 64; w++) {
-                const int wv = wave_i[w];
-                if (w < (tid >> 6)) pre = max(pre, wv);
-                tot = max(tot, wv);
+            int pre = carry_g, totg = carry_g, suf = carry_h, toth = carry_h;
+            for (int w = 0; w < NT / 64; w++) {
+                const int gv = wave_g[w], hv = wave_h[w];
+                if (w < myw) pre = max(pre, gv);
+                totg = max(totg, gv);
+                if (w > myw) suf = min(suf, hv);
+                toth = min(toth, hv);
             }
             a = max(a, pre);
-            if (p < ku) gcell[p] = a;
-            carry_g = tot;
-            __syncthreads();
-        }
-        // suffix min of H_p
-        int carry_h = G + 1;
-        for (int rd = rounds - 1; rd >= 0; rd--) {
-            const int p = rd * KM_THREADS + tid;
-            int b = hp_r[rd];
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_down(b, off);
-                if ((tid & 63) + off < 64) b = min(b, o);
-            }
-            if ((tid & 63) == 0) wave_i[tid >> 6] = b;
-            __syncthreads();
-            int suf = carry_h, tot = carry_h;
-            for (int w = 0; w < KM_THREADS / 64; w++) {
-                const int wv = wave_i[w];
-                if (w > (tid >> 6)) suf = min(suf, wv);
-                tot = min(tot, wv);
-            }
             b = min(b, suf);
-            if (p < ku) hcell[p] = b;
-            carry_h = tot;
+            const int pg = rg * NT + tid, ph = rh * NT + tid;
+            if (pg < ku) gcell[pg] = a;
+            if (ph < ku) hcell[ph] = b;
+            carry_g = totg; carry_h = toth;
             __syncthreads();
         }
     }
     FSTAMP(5);
     FSTAMP(6);
     // ---- the cell table itself is built by k_cells (many workgroups: one CU is VALU-bound on it)
-    for (int p = tid; p < ku; p += KM_THREADS) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
+    for (int p = tid; p < ku; p += NT) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
     if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = 1; }
     FSTAMP(7);
 #undef FSTAMP
@@ -1563,7 +1589,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     const int g = blockIdx.x * KM_THREADS + threadIdx.x;
     if ((int)(blockIdx.x * KM_THREADS) >= G) return;
     KmTab *tab = &ws->tab[ws->cur];
-    const int ku = tab->ku;
+    const int ku = ws->ku_cur;
     for (int p = threadIdx.x; p < ku; p += KM_THREADS) { gcell[p] = tab->gc[p]; hcell[p] = tab->hc[p]; }
     __syncthreads();
     if (g >= G) return;
@@ -1587,9 +1613,11 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     tab->cell[g] = (uint16_t)(field | (c << KM_P_BITS));
 }
 
-static int km_launch_finalize(KmWs *w, int mode, int resume, void *stream, void *host_mapped = nullptr, uint64_t ticket = 0)
+static int km_launch_finalize(KmWs *w, int k, int mode, int resume, void *stream, void *host_mapped = nullptr, uint64_t ticket = 0)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, mode, resume);
+    if (k > 0 && k <= 64) hipLaunchKernelGGL(k_finalize<64>, dim3(1), dim3(64), 0, S(stream), w, mode, resume);
+    else if (k > 0 && k <= 256) hipLaunchKernelGGL(k_finalize<256>, dim3(1), dim3(256), 0, S(stream), w, mode, resume);
+    else hipLaunchKernelGGL(k_finalize<KM_THREADS>, dim3(1), dim3(KM_THREADS), 0, S(stream), w, mode, resume);
     LAUNCHCHK("k_finalize");
     if (mode != FIN_PACK_ONLY) {
         unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
@@ -1647,7 +1675,7 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     hipLaunchKernelGGL(k_km_init, dim3(1), dim3(KM_THREADS), 0, S(stream), w, *p, glog2, rlog2, inv, centers_init_dev);
     LAUNCHCHK("k_km_init");
-    return km_launch_finalize(w, FIN_INIT, 0, stream);
+    return km_launch_finalize(w, p->k, FIN_INIT, 0, stream);
 }
 
 static int km_grid(int64_t n, size_t lds_bytes)
@@ -1796,7 +1824,7 @@ extern "C" int nnc_kmeans_accumulate(const float *x, void *ws, const nnc_kmeans_
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-    return km_launch_finalize(w, FIN_PACK_ONLY, 0, stream);
+    return km_launch_finalize(w, p.k, FIN_PACK_ONLY, 0, stream);
 }
 
 extern "C" int64_t *nnc_kmeans_partials(void *ws)
@@ -1808,7 +1836,7 @@ extern "C" int64_t *nnc_kmeans_partials(void *ws)
 extern "C" int nnc_kmeans_finalize(void *ws, int resume, void *stream)
 {
     if (!ws) return fail(NNC_EINVAL, "nnc_kmeans_finalize: null workspace");
-    return km_launch_finalize(reinterpret_cast<KmWs *>(ws), FIN_FROM_PARTIALS, resume ? 1 : 0, stream);
+    return km_launch_finalize(reinterpret_cast<KmWs *>(ws), 0 /* k not known here: full width */, FIN_FROM_PARTIALS, resume ? 1 : 0, stream);
 }
 
 extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *stream)
@@ -1822,7 +1850,7 @@ extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_par
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-        if ((rc = km_launch_finalize(w, FIN_FROM_SHARDS, 0, stream))) return rc;
+        if ((rc = km_launch_finalize(w, p.k, FIN_FROM_SHARDS, 0, stream))) return rc;
     }
     return NNC_OK;
 }
@@ -1876,7 +1904,7 @@ extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_km
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
         const bool last = i == iters - 1;
-        if ((rc = km_launch_finalize(w, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
+        if ((rc = km_launch_finalize(w, p.k, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
     }
     return NNC_OK;
 }

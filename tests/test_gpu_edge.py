@@ -60,10 +60,13 @@ def test_many_centroids_16bit_labels(km_mod, k):
     assert model.labels_.max() == k - 1 or model.labels_.max() < k
 
 
-def test_sorted_and_unsorted_iterations_agree(km_mod):
+@pytest.mark.parametrize("n,k", [(400_000, 64), (700, 16), (5_000, 16), (70_001, 256)])
+def test_sorted_and_unsorted_iterations_agree(km_mod, n, k):
+    """Both forms of the fit (value-sorted copy with windowed relocation; the vector as it stands with the full-pass
+    relocation) give the same model; which one a tensor gets is a matter of its length only."""
     kmeans, _ = km_mod
-    x = synth.weights((400_000,), 77)
-    init = np.linspace(x.min(), x.max(), 64).astype(np.float32)
+    x = synth.weights((n,), 77 + n)
+    init = np.linspace(x.min(), x.max(), k).astype(np.float32)
     a, _ = kmeans.DeviceKMeans(torch.from_numpy(x).cuda(), init, sort=True).fit()
     b, _ = kmeans.DeviceKMeans(torch.from_numpy(x).cuda(), init, sort=False).fit()
     assert a.n_iter_ == b.n_iter_ and np.array_equal(a.labels_, b.labels_)

@@ -25,3 +25,13 @@ run(); torch.cuda.synchronize()
 t0 = time.perf_counter(); bits, iters, reloc = run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"{len(tensors)} tensors, {total/1e6:.1f} M weights: {dt*1e3:.1f} ms -> {total/dt/1e9:.2f} G weights/s; {iters} Lloyd iterations, {reloc} relocations, "
       f"Huffman {bits/total:.3f} bits/weight")
+# per size class (each layer timed on its own, synchronised either side)
+by = {}
+for _, t in tensors:
+    c = t.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = pipeline.compress_layer(c, q=1.0, bits=4, mode="linear", huffman=True, want_values=True)
+    torch.cuda.synchronize(); d = time.perf_counter() - t0
+    e = by.setdefault(t.numel(), [0, 0.0, 0]); e[0] += 1; e[1] += d; e[2] += r.model.n_iter_
+for n in sorted(by):
+    c, d, it = by[n]
+    print(f"  n={n:>9}: {c:3d} tensors, {d/c*1e3:7.3f} ms each, {it/c:5.1f} iterations each, {d*1e3:7.1f} ms in all")
