@@ -133,7 +133,7 @@ __device__ __forceinline__ float xform1(float v, float mean)
 // The ragged last chunk (m < 8192 elements): the generic workgroup-parallel pairwise sum.
 struct PwFrame { int start, len, stage; float left; };
 struct PwHeap { int start[256]; int len[256]; float val[256]; };
-template <typename F> __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp);
+template <bool WAVE_ONLY = false, typename F> __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp);
 
 // one wave per full chunk; 4 waves (4 chunks) per workgroup; with a ragged last chunk the grid has one more
 // workgroup, which sums it (so that it runs beside the others instead of in a launch of its own)
@@ -666,6 +666,10 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 #define KM_P_MASK 2047u
 #define KM_OVF_MAX 1024     // cells with a saturated count keep their exact candidate range in a side list
 #define KM_OVF_ALL 2047u    // ... or, if even that list is full, scan every centre
+// Few centres and a small grid: k_finalize builds the cell table itself (its one busy wave plus fifteen helper waves
+// that sleep until the zones are known), which saves the k_cells launch where a launch is a third of the iteration.
+#define KM_FUSE_GLOG2 11
+#define KM_FUSE_KMAX 64
 #ifndef KM_RING
 #define KM_RING 4 // float4 loads kept in flight per thread
 #endif
@@ -739,7 +743,7 @@ static void km_defaults(const nnc_kmeans_params *p, int *glog2, int *rlog2)
     }
     if (r > 5) r = 5;
     int g = p->grid_log2;
-    if (g <= 0) g = 14;
+    if (g <= 0) g = p->k <= 32 ? KM_FUSE_GLOG2 - 1 : (p->k <= KM_FUSE_KMAX ? KM_FUSE_GLOG2 : 14); // few centres: a coarse grid leaves next to nothing to the general path
     if (g < 6) g = 6;
     if (g > 15) g = 15;
     // keep table + accumulators + candidates inside 156 KiB
@@ -1122,7 +1126,7 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
 // heap in LDS (node i -> children 2i, 2i+1; depth <= 7), leaves are summed by 8 lanes each, and
 // the tree is folded level by level.  F(i) returns element i.  All threads get the result.
 
-template <typename F>
+template <bool WAVE_ONLY, typename F>
 __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 {
     const int tid = threadIdx.x, nthr = blockDim.x;
@@ -1143,7 +1147,8 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
             }
             if (tid == 0) hp->val[1] = res;
         }
-        __syncthreads();
+        if (WAVE_ONLY) wave_lds_fence(); // (the caller is a single wave and n <= LEAF: no workgroup barrier anywhere)
+        else __syncthreads();
         return hp->val[1];
     }
     for (int i = tid; i < 256; i += nthr) { hp->start[i] = 0; hp->len[i] = 0; hp->val[i] = 0.0f; }
@@ -1206,9 +1211,17 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 
 // NT threads: a fit with few centres runs it as a single wave (64) or four (256), for which the many barriers and
 // wave-to-wave hand-overs of the scans cost next to nothing; NT >= k is all it needs (k > 1024 takes two rounds of 1024).
-template <int NT>
-__global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume)
+// WAVE (NT == 64 only): the body is run by ONE wave of a larger workgroup, so it may not use workgroup barriers; the
+// wave's own lock step (plus a compiler fence) orders its LDS traffic.  Returns true if new zones were left
+// (gcell / hcell / ku_out = {ku, cur} filled), i.e. the cell table has to be rebuilt.
+template <int NT, bool ONEWAVE>
+__device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out)
 {
+    static_assert(!ONEWAVE || NT == 64, "the barrier-free form is for a single wave");
+#define FIN_SYNC() do { if (ONEWAVE) wave_lds_fence(); else __syncthreads(); } while (0)
+#define FIN_OR(x) (ONEWAVE ? (int)__any(x) : __syncthreads_or(x))
+#define FIN_AND(x) (ONEWAVE ? (int)__all(x) : __syncthreads_and(x))
+#define FIN_COUNT(x) (ONEWAVE ? (int)__popcll(__ballot(x)) : __syncthreads_count(x))
     __shared__ long long sum_o[NNC_KMAX];
     __shared__ long long cnt_o[NNC_KMAX];
     __shared__ __align__(16) float cnew[NNC_KMAX];
@@ -1218,7 +1231,6 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
     __shared__ unsigned long long sh_key;
     __shared__ int ovf_n;
     __shared__ PwHeap heap;
-    __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
     __shared__ float cu[NNC_KMAX];     // distinct sorted centre values
     __shared__ uint16_t sou[NNC_KMAX]; // their (lowest) original indices
     __shared__ double wave_a[NT / 64], wave_b[NT / 64];
@@ -1235,19 +1247,19 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
     const float tol_v = ws->p.tol, p_lo = ws->p.lo, p_hi = ws->p.hi, inv_f = ws->inv;
     const int ku0 = ws->tab[0].ku, ku1 = ws->tab[1].ku;
     int cur = ws->cur;
-    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) return;
-    if (mode == FIN_FROM_SHARDS && st_paused) return;
+    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) return false;
+    if (mode == FIN_FROM_SHARDS && st_paused) return false;
     if (mode == FIN_PACK_ONLY && (st_done | st_paused)) {
         // no new iteration was accumulated: hand the all-reduce this rank's own sums again,
         // so that reducing an idle iteration leaves `partials` unchanged
         const int k2 = 2 * k;
         for (int i = tid; i < k2; i += NT) ws->partials[i] = ws->partials_local[i];
-        return;
+        return false;
     }
-    if (mode == FIN_FROM_PARTIALS && st_paused && !resume) return;
+    if (mode == FIN_FROM_PARTIALS && st_paused && !resume) return false;
     if (resume && reloc_fail) { // unproven windowed selection: stay paused, tell the host
         if (tid == 0) ws->st.paused = 2;
-        return;
+        return false;
     }
 
     // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept its
@@ -1272,7 +1284,7 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
         const KmTab *tab = &ws->tab[cur];
         const int ku_cur = cur ? ku1 : ku0;
         for (int j = tid; j < k; j += NT) { sum_o[j] = 0; cnt_o[j] = 0; } // duplicates of a centre own nothing
-        __syncthreads();
+        FIN_SYNC();
         for (int p = tid; p < ku_cur; p += NT) {
             long long s = 0;
             unsigned long long c = 0;
@@ -1283,16 +1295,16 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             }
             sum_o[o] = s; cnt_o[o] = (long long)c;
         }
-        __syncthreads();
+        FIN_SYNC();
         for (int j = tid; j < k; j += NT) {
             ws->partials[j] = sum_o[j]; ws->partials[k + j] = cnt_o[j];
             ws->partials_local[j] = sum_o[j]; ws->partials_local[k + j] = cnt_o[j];
         }
-        if (mode == FIN_PACK_ONLY) return;
+        if (mode == FIN_PACK_ONLY) return false;
     } else if (mode == FIN_FROM_PARTIALS) {
         for (int j = tid; j < k; j += NT) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
-    __syncthreads();
+    FIN_SYNC();
     if (track) {
         int count_diff = 0;
         for (int j = tid, r = 0; j < k; j += NT, r++) {
@@ -1300,7 +1312,7 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             count_diff |= (pc[r] != c);
             ws->prev_counts[j] = c;
         }
-        const int any_diff = __syncthreads_or(count_diff);
+        const int any_diff = FIN_OR(count_diff);
         if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
     }
     FSTAMP(1);
@@ -1310,31 +1322,31 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
         int my_empty = 0;
         for (int j = tid; j < k; j += NT) my_empty += (cnt_o[j] == 0);
         if (tid == 0) sh_key = 0ull;
-        const int n_empty = __syncthreads_count(my_empty);
+        const int n_empty = FIN_COUNT(my_empty);
         if (n_empty > 0 && !resume) {
             int tot_empty = 0;
             if (tid == 0) {
                 for (int j = 0; j < k; j++) tot_empty += (cnt_o[j] == 0); // rare path, exact count
                 ws->st.paused = 1; ws->st.n_empty = tot_empty;
             }
-            return;
+            return false;
         }
         // ---- _average_centers
         for (int j = tid; j < k; j += NT)
             if (cnt_o[j] > 0) cnew[j] = (float)ldexp((double)sum_o[j] / (double)cnt_o[j], -Sft);
-        __syncthreads();
+        FIN_SYNC();
         if (n_empty > 0) { // only after a relocation that bailed out (all samples on their centres)
             // first index of the largest count (key = count, then lowest index)
             for (int j = tid; j < k; j += NT)
                 atomicMax(&sh_key, ((unsigned long long)cnt_o[j] << 11) | (unsigned long long)(2047 - j));
-            __syncthreads();
+            FIN_SYNC();
             const int amax = 2047 - (int)(sh_key & 2047ull);
             for (int j = tid; j < k; j += NT)
                 if (cnt_o[j] <= 0) {
                     // sklearn copies centers[argmax] as it stands: averaged if argmax < j, raw sum otherwise
                     cnew[j] = (amax < j) ? cnew[amax] : (float)ldexp((double)sum_o[amax], -Sft);
                 }
-            __syncthreads();
+            FIN_SYNC();
         }
         FSTAMP(2);
         // ---- _center_shift and the tolerance test
@@ -1344,8 +1356,8 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             float sft = (float)sqrt((double)s2);
             sq[j] = sft * sft;
         }
-        __syncthreads();
-        const float tot = block_pairwise_sum([&](int i) { return sq[i]; }, k, &heap);
+        FIN_SYNC();
+        const float tot = block_pairwise_sum<ONEWAVE>([&](int i) { return sq[i]; }, k, &heap);
         if (tid == 0) {
             int iter = st_iter + 1;
             int done = 0;
@@ -1357,10 +1369,10 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
         }
         cur ^= 1;
         for (int j = tid; j < k; j += NT) ws->c[cur][j] = cnew[j];
-        __syncthreads();
+        FIN_SYNC();
     } else {
         for (int j = tid; j < k; j += NT) cnew[j] = ws->c[cur][j];
-        __syncthreads();
+        FIN_SYNC();
     }
 
     FSTAMP(3);
@@ -1380,7 +1392,7 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
                 ok &= (va < vb) || (va == vb && a < b);
             }
         }
-        still_sorted = __syncthreads_and(ok);
+        still_sorted = FIN_AND(ok);
         // nearly sorted (two neighbours changed places): a few odd-even transposition passes repair it
         for (int pass = 0; pass < 3 && !still_sorted; pass++) {
             for (int parity = 0; parity < 2; parity++) {
@@ -1390,14 +1402,14 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
                     const uint16_t a = so[p], b = so[p + 1];
                     if (!((va < vb) || (va == vb && a < b))) { cs[p] = vb; cs[p + 1] = va; so[p] = b; so[p + 1] = a; }
                 }
-                __syncthreads();
+                FIN_SYNC();
             }
             int ok2 = 1;
             for (int p = tid; p + 1 < k; p += NT) {
                 const float va = cs[p], vb = cs[p + 1];
                 ok2 &= (va < vb) || (va == vb && so[p] < so[p + 1]);
             }
-            still_sorted = __syncthreads_and(ok2);
+            still_sorted = FIN_AND(ok2);
         }
     }
     FSTAMP(8);
@@ -1424,7 +1436,7 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             if (j < k && part == 0) { cs[rank] = v; so[rank] = (uint16_t)j; }
         }
     }
-    __syncthreads();
+    FIN_SYNC();
     FSTAMP(9);
     // Equal centres: the first one (lowest original index; the sort breaks ties that way) takes every
     // tie, the others can never win.  Keep only distinct values in the search tables.
@@ -1445,12 +1457,12 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             const unsigned long long bal = __ballot(first);
             const int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
             if ((tid & 63) == 0) wave_i[tid >> 6] = __popcll(bal);
-            __syncthreads();
+            FIN_SYNC();
             int pre = carry, tot = carry;
             for (int w = 0; w < NT / 64; w++) { const int wv = wave_i[w]; if (w < (tid >> 6)) pre += wv; tot += wv; }
             if (first) { cu[pre + before] = v; sou[pre + before] = (uint16_t)o; }
             carry = tot;
-            __syncthreads();
+            FIN_SYNC();
         }
         ku = carry;
     }
@@ -1462,7 +1474,7 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
         tab->orig[p] = sou[p];
     }
     if (tid == 0) { tab->ku = ku; ws->ku_cur = ku; ovf_n = 0; }
-    __syncthreads();
+    FIN_SYNC();
     FSTAMP(4);
     // ---- zone of every centre: the x-interval [left, right] on which it can be the float32 arg-min,
     // turned at once into cells: cell g covers x~ - lo in [g * ra, (g+1) * rb]; centre p can open
@@ -1543,7 +1555,7 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             }
             if (lane == 63) wave_g[myw] = a;
             if (lane == 0) wave_h[myw] = b;
-            __syncthreads();
+            FIN_SYNC();
             int pre = carry_g, totg = carry_g, suf = carry_h, toth = carry_h;
             for (int w = 0; w < NT / 64; w++) {
                 const int gv = wave_g[w], hv = wave_h[w];
@@ -1558,16 +1570,89 @@ __global__ __launch_bounds__(NT) void k_finalize(KmWs *__restrict__ ws, int mode
             if (pg < ku) gcell[pg] = a;
             if (ph < ku) hcell[ph] = b;
             carry_g = totg; carry_h = toth;
-            __syncthreads();
+            FIN_SYNC();
         }
     }
     FSTAMP(5);
     FSTAMP(6);
     // ---- the cell table itself is built by k_cells (many workgroups: one CU is VALU-bound on it)
     for (int p = tid; p < ku; p += NT) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
-    if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = 1; }
+    if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = ONEWAVE ? 0 : 1; ku_out[0] = ku; ku_out[1] = cur; }
     FSTAMP(7);
 #undef FSTAMP
+#undef FIN_SYNC
+#undef FIN_OR
+#undef FIN_AND
+#undef FIN_COUNT
+    return true;
+}
+
+
+// cell g -> candidate range [first p with gc[p] >= g, last p with hc[p] <= g] (both monotone in g), packed.  The first
+// and last cells are open-ended: everything below lo / above hi is clamped into them.  Crowded cells go to the side
+// list (*n_ovf, ovf[]; readers clamp the count to KM_OVF_MAX).
+__device__ __forceinline__ uint16_t km_cell_entry(int g, int G, int ku, const int *gcell, const int *hcell, int *n_ovf, unsigned *ovf)
+{
+    int l = 0, h = ku - 1;
+    while (l < h) { const int m = (l + h) >> 1; if (gcell[m] >= g) h = m; else l = m + 1; }
+    const int plo = l;
+    l = 0; h = ku - 1;
+    while (l < h) { const int m = (l + h + 1) >> 1; if (hcell[m] <= g) l = m; else h = m - 1; }
+    const int phi = l;
+    int lo_p = (g == 0) ? 0 : plo;       // below lo nothing exists, but keep cell 0 / G-1 conservative
+    int hi_p = (g == G - 1) ? ku - 1 : phi;
+    if (hi_p < lo_p) { lo_p = 0; hi_p = ku - 1; }
+    int c = hi_p - lo_p;
+    int field = lo_p;
+    if (c >= KM_CNT_SAT) {
+        c = KM_CNT_SAT;
+        const int idx = atomicAdd(n_ovf, 1);
+        if (idx < KM_OVF_MAX) { ovf[idx] = (unsigned)lo_p | ((unsigned)hi_p << 16); field = idx; }
+        else field = (int)KM_OVF_ALL;
+    }
+    return (uint16_t)(field | (c << KM_P_BITS));
+}
+
+// FUSED: NT = 64 busy threads inside a KM_THREADS workgroup.  The helpers sleep on an LDS flag while the first wave
+// runs the body, then all of them turn the zones into the cell table (a few cells per thread) -- no k_cells launch.
+// The last launch of a batch may carry the host's look-in (nnc_kmeans_iterate_publish): once the state is final the
+// status block and the ticket go out here when no k_cells launch follows to carry them.
+template <int NT, bool FUSED>
+__global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume,
+                                                                      nnc_kmeans_status *host_st, unsigned long long *host_ticket,
+                                                                      unsigned long long ticket)
+{
+    __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
+    __shared__ int fin_go, fin_kc[2], fin_novf; // fin_kc: {distinct centres, current table} from the body
+    const int tid = threadIdx.x;
+    if (FUSED) {
+        const int glog2 = ws->glog2; // (constant over the fit: the helpers may read it at once)
+        if (tid == 0) { fin_go = 0; fin_novf = 0; }
+        __syncthreads();
+        if (tid < NT) {
+            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc);
+            if (tid == 0) __hip_atomic_store(&fin_go, built ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        int go; // every path of the body ends in the store above, so the wait is bounded by the body's run time
+        while ((go = __hip_atomic_load(&fin_go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(1);
+        if (go == 1) {
+            KmTab *tab = &ws->tab[fin_kc[1]];
+            const int G = 1 << glog2, ku = fin_kc[0];
+            for (int g = tid; g < G; g += KM_THREADS) tab->cell[g] = km_cell_entry(g, G, ku, gcell, hcell, &fin_novf, tab->ovf);
+            __syncthreads();
+            if (tid == 0) tab->n_ovf = fin_novf;
+        }
+    } else {
+        km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc);
+    }
+    if (host_st) {
+        __syncthreads();
+        if (tid == 0) {
+            *host_st = ws->st;
+            __threadfence_system();
+            *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
+        }
+    }
 }
 
 // cell g -> candidate range [first p with gc[p] >= g, last p with hc[p] <= g] (both monotone in g);
@@ -1593,37 +1678,30 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     for (int p = threadIdx.x; p < ku; p += KM_THREADS) { gcell[p] = tab->gc[p]; hcell[p] = tab->hc[p]; }
     __syncthreads();
     if (g >= G) return;
-    int l = 0, h = ku - 1;
-    while (l < h) { const int m = (l + h) >> 1; if (gcell[m] >= g) h = m; else l = m + 1; }
-    const int plo = l;
-    l = 0; h = ku - 1;
-    while (l < h) { const int m = (l + h + 1) >> 1; if (hcell[m] <= g) l = m; else h = m - 1; }
-    const int phi = l;
-    int lo_p = (g == 0) ? 0 : plo;       // below lo nothing exists, but keep cell 0 / G-1 conservative
-    int hi_p = (g == G - 1) ? ku - 1 : phi;
-    if (hi_p < lo_p) { lo_p = 0; hi_p = ku - 1; }
-    int c = hi_p - lo_p;
-    int field = lo_p;
-    if (c >= KM_CNT_SAT) {
-        c = KM_CNT_SAT;
-        const int idx = atomicAdd(&tab->n_ovf, 1); // readers clamp the count to KM_OVF_MAX
-        if (idx < KM_OVF_MAX) { tab->ovf[idx] = (unsigned)lo_p | ((unsigned)hi_p << 16); field = idx; }
-        else field = (int)KM_OVF_ALL;
-    }
-    tab->cell[g] = (uint16_t)(field | (c << KM_P_BITS));
+    tab->cell[g] = km_cell_entry(g, G, ku, gcell, hcell, &tab->n_ovf, tab->ovf);
 }
 
-static int km_launch_finalize(KmWs *w, int k, int mode, int resume, void *stream, void *host_mapped = nullptr, uint64_t ticket = 0)
+static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume, void *stream, void *host_mapped = nullptr,
+                              uint64_t ticket = 0)
 {
-    if (k > 0 && k <= 64) hipLaunchKernelGGL(k_finalize<64>, dim3(1), dim3(64), 0, S(stream), w, mode, resume);
-    else if (k > 0 && k <= 256) hipLaunchKernelGGL(k_finalize<256>, dim3(1), dim3(256), 0, S(stream), w, mode, resume);
-    else hipLaunchKernelGGL(k_finalize<KM_THREADS>, dim3(1), dim3(KM_THREADS), 0, S(stream), w, mode, resume);
+    // p == nullptr: the caller does not know the fit's parameters (nnc_kmeans_finalize): full width, k_cells builds the table
+    const int k = p ? p->k : 0;
+    bool fused = false;
+    if (p && mode != FIN_PACK_ONLY) { int glog2, rlog2; km_defaults(p, &glog2, &rlog2); fused = p->k <= KM_FUSE_KMAX && glog2 <= KM_FUSE_GLOG2; }
+    const bool cells = mode != FIN_PACK_ONLY && !fused;
+    unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
+    nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
+    unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
+    nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
+#define KM_LAUNCH_FIN(NT, FUSED, THREADS) hipLaunchKernelGGL((k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket)
+    if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
+    else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
+    else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256);
+    else KM_LAUNCH_FIN(KM_THREADS, false, KM_THREADS);
+#undef KM_LAUNCH_FIN
     LAUNCHCHK("k_finalize");
-    if (mode != FIN_PACK_ONLY) {
-        unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
-        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w,
-                           reinterpret_cast<nnc_kmeans_status *>(hb),
-                           reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr), (unsigned long long)ticket);
+    if (cells) {
+        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, hs, ht, (unsigned long long)ticket);
         LAUNCHCHK("k_cells");
     }
     return NNC_OK;
@@ -1675,7 +1753,7 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     hipLaunchKernelGGL(k_km_init, dim3(1), dim3(KM_THREADS), 0, S(stream), w, *p, glog2, rlog2, inv, centers_init_dev);
     LAUNCHCHK("k_km_init");
-    return km_launch_finalize(w, p->k, FIN_INIT, 0, stream);
+    return km_launch_finalize(w, p, FIN_INIT, 0, stream);
 }
 
 static int km_grid(int64_t n, size_t lds_bytes)
@@ -1824,7 +1902,7 @@ extern "C" int nnc_kmeans_accumulate(const float *x, void *ws, const nnc_kmeans_
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-    return km_launch_finalize(w, p.k, FIN_PACK_ONLY, 0, stream);
+    return km_launch_finalize(w, &p, FIN_PACK_ONLY, 0, stream);
 }
 
 extern "C" int64_t *nnc_kmeans_partials(void *ws)
@@ -1836,7 +1914,7 @@ extern "C" int64_t *nnc_kmeans_partials(void *ws)
 extern "C" int nnc_kmeans_finalize(void *ws, int resume, void *stream)
 {
     if (!ws) return fail(NNC_EINVAL, "nnc_kmeans_finalize: null workspace");
-    return km_launch_finalize(reinterpret_cast<KmWs *>(ws), 0 /* k not known here: full width */, FIN_FROM_PARTIALS, resume ? 1 : 0, stream);
+    return km_launch_finalize(reinterpret_cast<KmWs *>(ws), nullptr, FIN_FROM_PARTIALS, resume ? 1 : 0, stream);
 }
 
 extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *stream)
@@ -1850,7 +1928,7 @@ extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_par
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-        if ((rc = km_launch_finalize(w, p.k, FIN_FROM_SHARDS, 0, stream))) return rc;
+        if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream))) return rc;
     }
     return NNC_OK;
 }
@@ -1904,7 +1982,7 @@ extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_km
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
         const bool last = i == iters - 1;
-        if ((rc = km_launch_finalize(w, p.k, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
+        if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
     }
     return NNC_OK;
 }
@@ -2712,7 +2790,7 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
                        reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
                        reinterpret_cast<long long *>(keys), 1, hist0);
     LAUNCHCHK("k_reloc_select");
-    return nnc_kmeans_finalize(ws, 1, stream);
+    return km_launch_finalize(reinterpret_cast<KmWs *>(ws), p, FIN_FROM_PARTIALS, 1, stream);
 }
 
 // Sharded vector: every rank selects (and proves) its own n_empty farthest samples from its shard's windows; the ranks
