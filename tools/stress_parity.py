@@ -12,14 +12,14 @@ ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 bad = 0
 t0 = time.time()
 for case in range(ncases):
-    n = int(rng.choice([66_000, 70_001, 131_072, 200_003, 300_000, 450_000]))
+    n = int(rng.choice([600, 3_000, 20_000, 66_000, 70_001, 131_072, 200_003, 300_000, 450_000]))
     x = synth.weights((n,), 9000 + case, scale=float(rng.choice([0.05, 0.5, 3e-4])))
     kind = rng.randint(0, 5)
     if kind in (0, 1):
         x[np.abs(x) < np.float32(rng.uniform(0.2, 1.5)) * x.std()] = 0
     if kind == 2:
         x = (np.round(x / x.std() * rng.randint(3, 40)) * x.std() / 17).astype(np.float32)   # few distinct values
-    k = int(rng.choice([4, 16, 33, 64, 100, 257]))
+    k = int(rng.choice([2, 4, 8, 16, 32, 33, 64, 65, 100, 256, 257]))
     style = rng.randint(0, 5)
     lo, hi = float(x.min()), float(x.max())
     if style == 0:
