@@ -219,3 +219,18 @@ def test_weight_distribution_from_sorted_copy(km_mod):
         c = orc.get_weight_distribution(nzv)
         for u, v, w in zip(a, b, c):
             assert np.array_equal(u, v) and np.array_equal(u, w)
+
+
+@pytest.mark.parametrize("k", [2, 16, 32, 33, 64, 65, 256])
+@pytest.mark.parametrize("grid_log2", [0, 6, 10, 11, 12, 14, 15])
+def test_cell_grid_size_does_not_change_the_fit(km_mod, k, grid_log2):
+    """The E-step's cell grid is an accelerator, never an approximation: every size gives the oracle's fit, and so do
+    both builders of the table -- k_finalize's own (up to 64 centres on grids of up to 2^11 cells, which is also
+    what grid_log2 = 0, the default, selects there) and k_cells (the rest).  Crowded initial centres make cells
+    with many candidates (the side list) on the coarse grids."""
+    kmeans, _ = km_mod
+    x = synth.weights((40_000,), 4242 + k)
+    x[np.abs(x) < np.float32(0.8) * x.std()] = 0
+    init = np.concatenate([np.linspace(x.min(), x.max(), k - k // 2), np.full(k // 2, np.float32(1e-3))]).astype(np.float32)
+    init[k // 2:] += np.arange(k - k // 2, dtype=np.float32)[: k - k // 2][: init[k // 2:].size] * np.float32(1e-7)
+    _check(kmeans, x, init, grid_log2=grid_log2)
