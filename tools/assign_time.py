@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Average duration of k_assign<accumulate> over one fit of the bench workload (in-library HIP events).
-   ABL=<n> selects an experimental kernel variant (nnc_debug_set_ablation); PRUNE=0 for the dense vector."""
+   ABL=<n> selects an experimental kernel variant (nnc_debug_set_ablation); PRUNE=0 for the dense vector; GRID=<log2> the cell grid."""
 import ctypes, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ for abl in [int(a) for a in os.environ.get("ABL", "0").split(",")]:
     nat.check(L.nnc_debug_set_ablation(abl))
     res = []
     for rep in range(3):
-        km = kmeans.DeviceKMeans(x, space)
+        km = kmeans.DeviceKMeans(x, space, grid_log2=int(os.environ.get("GRID", "0")))
         nat.check(L.nnc_profile_begin(400))
         model, _ = km.fit(False)
         torch.cuda.synchronize()
