@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import threading
 import time
 
 import numpy as np
@@ -70,6 +71,32 @@ def _allreduce_(t: torch.Tensor, op, group):
     return t
 
 
+_TLS = threading.local()
+
+
+def _pinned_landing():
+    """One pinned float32[6] + int64[2] per host thread for the statistics read (allocating pinned memory per layer
+    costs more than the read)."""
+    if getattr(_TLS, "stats", None) is None:
+        _TLS.stats = (torch.empty(6, dtype=torch.float32, pin_memory=True), torch.empty(2, dtype=torch.int64, pin_memory=True))
+    return _TLS.stats
+
+
+def _status_landing(nbytes: int) -> torch.Tensor:
+    """The pinned status slots, one allocation per host thread (the pinned allocator's bookkeeping per fit costs more
+    than a look-in).  Safe to share between the fits of a thread: a look-in is waited for before the next one is
+    published, and tickets are unique."""
+    buf = getattr(_TLS, "status", None)
+    if buf is None or buf.numel() < nbytes:
+        buf = _TLS.status = torch.zeros(nbytes, dtype=torch.uint8, pin_memory=True)
+    return buf
+
+
+def _next_ticket() -> int:
+    _TLS.ticket = getattr(_TLS, "ticket", 0) + 1
+    return _TLS.ticket
+
+
 class LayerStats:
     """NumPy-exact mean / variance, min / max (over all weights and over the non-zero ones) and the counts of
     negative and zero weights of one vector (this rank's shard for the counts), fetched with ONE host
@@ -89,8 +116,7 @@ class LayerStats:
             from . import sharding
 
             mm = torch.cat([sharding.allreduce_minmax(mm[:2].contiguous(), group), sharding.allreduce_minmax(mm[2:].contiguous(), group)])
-        pin_f = torch.empty(6, dtype=torch.float32, pin_memory=True)
-        pin_i = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        pin_f, pin_i = _pinned_landing()   # (the stream is synchronised before anybody else can use them)
         pin_f.copy_(torch.cat([mean_d, var_d, mm]), non_blocking=True)
         pin_i.copy_(signs, non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
@@ -193,12 +219,12 @@ class DeviceKMeans:
         # two slots of (status block, ticket): a look-in alternates between them, so that one may still be in flight
         # (published behind a speculative batch) while the host reads the other
         ssz = ctypes.sizeof(nat.KMeansStatus) + 8
-        self._status_pin = torch.zeros(2 * ssz, dtype=torch.uint8, pin_memory=True)
+        self._status_pin = _status_landing(2 * ssz)   # shared by the fits of this process: tickets never repeat (_next_ticket)
         self._slot_addr = [self._status_pin.data_ptr() + i * ssz for i in range(2)]
         self._slot_status = [nat.KMeansStatus.from_address(a) for a in self._slot_addr]
         self._slot_ticket = [ctypes.c_uint64.from_address(a + ctypes.sizeof(nat.KMeansStatus)) for a in self._slot_addr]
         self._ticket = 0
-        self._hist_pin = torch.empty(4096, dtype=torch.int64, pin_memory=True)
+        self._hist_pin = None   # pinned landing zone of the full-pass relocation's histogram, made on first use
         # The iterations stream a value-sorted copy (same sums in any order, far fewer LDS atomics);
         # labels, values and relocation distances always come from the original vector.
         if sort is None:
@@ -218,7 +244,7 @@ class DeviceKMeans:
         """Enqueue a look-in: a one-thread kernel writes the status block into pinned host memory, then a ticket.
         Returns the ticket; wait(ticket) polls for it.  (A few microseconds instead of a copy command plus a stream
         synchronisation; and the host may enqueue more work before it waits.)  At most two may be outstanding."""
-        self._ticket += 1
+        self._ticket = _next_ticket()
         nat.check(self.L.nnc_kmeans_status_publish(self.ws.data_ptr(), self._slot_addr[self._ticket & 1], self._ticket, self.stream))
         return self._ticket
 
@@ -244,7 +270,7 @@ class DeviceKMeans:
         if self.group is not None:
             self.iterate(iters)
             return self.status()
-        self._ticket += 1
+        self._ticket = _next_ticket()
         nat.check(self.L.nnc_kmeans_iterate_publish(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters),
                                                     self._slot_addr[self._ticket & 1], self._ticket, self.stream))
         return self.wait(self._ticket)
@@ -307,6 +333,8 @@ class DeviceKMeans:
             if not (shift == 19 and hist0 is not None):  # the first level may come for free from the distance pass
                 nat.check(self.L.nnc_topm_hist_f32(d.data_ptr(), n, shift, width, pshift, 0 if prefix is None else prefix,
                                                    hist.data_ptr(), self.stream))
+            if self._hist_pin is None:
+                self._hist_pin = torch.empty(4096, dtype=torch.int64, pin_memory=True)
             self._hist_pin.copy_(hist, non_blocking=True)
             torch.cuda.current_stream(self.dev).synchronize()
             h = self._hist_pin.numpy()
