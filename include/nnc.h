@@ -115,6 +115,14 @@ int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, in
 int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
                          void *stream);
 
+/* The statistics of one whole vector by one call (what np.mean / np.var of the reference's KMeans set-up,
+ * sklearn _kmeans.py:1011 / 286, and the pass above deliver one by one): out6_dev = {mean, variance (both
+ * NumPy-exact float32, as nnc_chunk_sums_f32 + nnc_fold_f32), min, max, min over the non-zeros, max over the
+ * non-zeros}, signs_dev = {#negative, #zero}.  n > 0; ws: nnc_layer_stats_workspace_bytes(n) bytes, 256-byte aligned. */
+size_t nnc_layer_stats_workspace_bytes(int64_t n);
+int nnc_layer_stats_f32(const float *x, int64_t n, float *out6_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
+                        void *stream);
+
 /* counts_dev[b] += #{ i : steps[b] <= x[i] < steps[b+1] }, b = 0..30 (caller zeroes counts_dev). */
 int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps32_dev, int64_t *counts_dev,
                    void *stream);

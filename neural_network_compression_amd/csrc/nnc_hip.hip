@@ -548,6 +548,30 @@ extern "C" int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, i
     return minmax_impl(x, n, 0, out_dev, nullptr, signs_dev, ws, ws_bytes, stream);
 }
 
+// Everything LayerStats wants of one (whole, single-GPU) vector, enqueued by one call: NumPy-exact mean and variance
+// (the two chunk-sum passes and their folds) and the min / max / sign pass.
+extern "C" size_t nnc_layer_stats_workspace_bytes(int64_t n)
+{
+    const size_t nch = (size_t)((n + NNC_CHUNK - 1) / NNC_CHUNK);
+    return ((2 * nch * sizeof(float) + 255) & ~(size_t)255) + nnc_minmax_workspace_bytes(n);
+}
+
+extern "C" int nnc_layer_stats_f32(const float *x, int64_t n, float *out6_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
+                                   void *stream)
+{
+    if (n <= 0 || !x || !out6_dev || !signs_dev || !ws) return fail(NNC_EINVAL, "nnc_layer_stats_f32: bad argument (n must be > 0)");
+    if (ws_bytes < nnc_layer_stats_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_layer_stats_f32: workspace too small");
+    const int64_t nch = (n + NNC_CHUNK - 1) / NNC_CHUNK;
+    float *c1 = reinterpret_cast<float *>(ws), *c2 = c1 + nch;
+    unsigned char *mm_ws = reinterpret_cast<unsigned char *>(ws) + ((2 * (size_t)nch * sizeof(float) + 255) & ~(size_t)255);
+    int rc;
+    if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, c1, stream))) return rc;
+    if ((rc = nnc_fold_f32(c1, nch, n, NNC_FOLD_MEAN, nullptr, out6_dev, stream))) return rc;           // [0] = mean
+    if ((rc = nnc_chunk_sums_f32(x, n, 1, out6_dev, c2, stream))) return rc;
+    if ((rc = nnc_fold_f32(c2, nch, n, NNC_FOLD_MEAN, nullptr, out6_dev + 1, stream))) return rc;       // [1] = variance
+    return minmax_impl(x, n, 0, out6_dev + 2, nullptr, signs_dev, mm_ws, nnc_minmax_workspace_bytes(n), stream); // [2..5]
+}
+
 // bin(x) = #{ steps[i] <= x } - 1 for non-decreasing steps (np.linspace is monotone), which is
 // exactly "steps[b] <= x < steps[b+1]"; x >= steps[31] (the maximum itself) falls in no bin.
 template <bool VEC>

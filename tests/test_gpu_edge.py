@@ -234,3 +234,22 @@ def test_cell_grid_size_does_not_change_the_fit(km_mod, k, grid_log2):
     init = np.concatenate([np.linspace(x.min(), x.max(), k - k // 2), np.full(k // 2, np.float32(1e-3))]).astype(np.float32)
     init[k // 2:] += np.arange(k - k // 2, dtype=np.float32)[: k - k // 2][: init[k // 2:].size] * np.float32(1e-7)
     _check(kmeans, x, init, grid_log2=grid_log2)
+
+
+@pytest.mark.parametrize("n", [1, 7, 768, 8192, 8193, 70_001, 1_000_003])
+def test_layer_statistics_in_one_call(km_mod, n):
+    """nnc_layer_stats_f32 (one enqueue) = numpy on the same float32 vector, bit for bit: mean, variance, min / max
+    over all and over the non-zero weights, sign counts."""
+    kmeans, _ = km_mod
+    x = synth.weights((n,), 31 + n)
+    if n > 4:
+        x[np.abs(x) < np.float32(0.7) * x.std()] = 0
+    st = kmeans.LayerStats(torch.from_numpy(x).cuda())
+    assert np.float32(st.mean).tobytes() == np.mean(x).tobytes() and np.float32(st.var).tobytes() == np.var(x).tobytes()
+    assert st.min == x.min() and st.max == x.max()
+    nzv = x[x != 0]
+    if nzv.size:
+        assert st.min_nonzero == nzv.min() and st.max_nonzero == nzv.max()
+    else:
+        assert np.isinf(st.min_nonzero) and np.isinf(st.max_nonzero)
+    assert st.n_negative == int((x < 0).sum()) and st.n_zero == int((x == 0).sum())
