@@ -2726,7 +2726,9 @@ static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmea
                        reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
                        reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev), hist0);
     LAUNCHCHK("k_reloc_windows");
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(64, (2 * (int64_t)window * (p->k + 1) + 4 * KM_THREADS - 1) / (4 * KM_THREADS))); // a few candidates per thread
+    // a candidate costs its thread two dependent reads (window record, sample): one or two per thread, not a queue of them
+    // (the windows double where centres are close, so there are about twice 2 * window * (k + 1) of them)
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (2 * (int64_t)window * (p->k + 1) + KM_THREADS - 1) / KM_THREADS));
     hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
                        reinterpret_cast<const int *>(meta_dev), cand_x, cand_d, (long long)cap, reinterpret_cast<const KmWs *>(ws), hist0);
     LAUNCHCHK("k_reloc_dist");
