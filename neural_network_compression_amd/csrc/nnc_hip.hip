@@ -2202,7 +2202,9 @@ extern "C" int nnc_topm_compact_f32(const float *d, const float *x, int64_t n, u
 // Nothing happens when the largest distance is zero.
 struct KmRelocLds { int empty_id[NNC_KMAX]; int wave_cnt[KM_THREADS / 64]; float cen[NNC_KMAX]; };
 
-__device__ void km_relocate_body(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys, KmRelocLds *lds)
+// first half: the current centres and the ordered list of the empty clusters into LDS (nothing here depends on the
+// keys, so a caller that still has the selection to do runs it up front and hides the loads); returns n_empty
+__device__ int km_relocate_prepare(const KmWs *__restrict__ ws, KmRelocLds *lds)
 {
     int *empty_id = lds->empty_id, *wave_cnt = lds->wave_cnt;
     float *cen = lds->cen;
@@ -2228,11 +2230,52 @@ __device__ void km_relocate_body(KmWs *__restrict__ ws, const long long *__restr
         carry = tot;
         __syncthreads();
     }
-    const int n_empty = carry;
+    return carry;
+}
+
+// second half: the edits.  A sample's old cluster is scikit-learn's float32 arg-min over ALL centres (first minimum);
+// with few samples a wave takes one (its lanes share the centres, the (distance, index) pairs are reduced
+// lexicographically), with many a thread does.
+__device__ void km_relocate_apply(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys, int n_empty, KmRelocLds *lds)
+{
+    const int *empty_id = lds->empty_id;
+    const float *cen = lds->cen;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = ws->p.k;
     const int m = n_empty < nkeys ? n_empty : nkeys;
     if (m == 0 || (keys[0] >> 32) == 0) return;
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
+    auto edit = [&](int i, float xc, int old) {
+        const long long v = (long long)fix_f32(xc, Sft);
+        const int nw = empty_id[i];
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[old]), (unsigned long long)(-v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[nw]), (unsigned long long)v);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[k + nw]), 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[k + old]), (unsigned long long)(-1ll));
+    };
+    if (m <= 4 * (KM_THREADS / 64)) {
+        for (int i = tid >> 6; i < m; i += KM_THREADS / 64) { // wave-uniform
+            const float xv = f32_from_ordered_bits((unsigned)(keys[i] & 0xFFFFFFFFll));
+            const float xc = xv - mean;
+            float best = INFINITY;
+            int old = 0x7fffffff;
+            for (int j = lane; j < k; j += 64) {
+                const float cv = cen[j];
+                const float dj = cv * cv + (-2.0f * (xc * cv));
+                if (dj < best) { best = dj; old = j; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ob = __shfl_xor(best, off);
+                const int oo = __shfl_xor(old, off);
+                if (ob < best || (ob == best && oo < old)) { best = ob; old = oo; }
+            }
+            if (old == 0x7fffffff) old = 0; // (every distance NaN: the scan below would have kept index 0)
+            if (lane == 0) edit(i, xc, old);
+        }
+        return;
+    }
     for (int i = tid; i < m; i += KM_THREADS) {
         const float xv = f32_from_ordered_bits((unsigned)(keys[i] & 0xFFFFFFFFll));
         const float xc = xv - mean;
@@ -2253,13 +2296,14 @@ __device__ void km_relocate_body(KmWs *__restrict__ ws, const long long *__restr
             const float dj = cen[j] * cen[j] + (-2.0f * (xc * cen[j]));
             if (dj < best) { best = dj; old = j; }
         }
-        const long long v = (long long)fix_f32(xc, Sft);
-        const int nw = empty_id[i];
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[old]), (unsigned long long)(-v));
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[nw]), (unsigned long long)v);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[k + nw]), 1ull);
-        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->partials[k + old]), (unsigned long long)(-1ll));
+        edit(i, xc, old);
     }
+}
+
+__device__ void km_relocate_body(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys, KmRelocLds *lds)
+{
+    const int n_empty = km_relocate_prepare(ws, lds);
+    km_relocate_apply(ws, keys, nkeys, n_empty, lds);
 }
 
 __global__ __launch_bounds__(KM_THREADS) void k_relocate(KmWs *__restrict__ ws, const long long *__restrict__ keys, int nkeys)
@@ -2498,6 +2542,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
 #define RSTAMP(i) do { if (strc && tid == 0) strc[3000 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RSTAMP(0);
     const int n_cand = meta[0];
+    // (the relocation's own inputs -- centres, list of empty clusters -- do not depend on the selection: fetched now)
+    const int n_empty_ws = do_relocate ? km_relocate_prepare(ws, &rl) : 0;
     {
         int bad0 = meta[2] ? 1 : 0;
         if (n_empty < 1 || n_cand < n_empty) bad0 |= 2;
@@ -2704,7 +2750,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     if (tid == 0) ws->reloc_fail = any_bad;
     if (any_bad || !do_relocate) return; // (sharded vector: the ranks first exchange their keys and their verdicts)
     __threadfence_block();
-    km_relocate_body(ws, keys_out, n_empty, &rl);
+    km_relocate_apply(ws, keys_out, n_empty, n_empty_ws, &rl);
     RSTAMP(5);
 #undef RSTAMP
 }
