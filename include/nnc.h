@@ -12,6 +12,8 @@
  * maintainer of the reference would add.
  *
  * Conventions
+ *   - one calling thread per (device, stream) at a time: all state lives in caller-owned workspaces; the few process-wide
+ *     caches (CU count, function attributes) are per device and thread safe, the bench profiler's event pool is locked;
  *   - every function returns 0 on success, a negative NNC_E* code on failure;
  *     nnc_last_error() gives the message of the calling thread's last failure;
  *   - pointers named *_dev / x / mask / labels are DEVICE pointers (hipMalloc'ed or
@@ -180,6 +182,11 @@ typedef struct nnc_kmeans_status {
     float tol;
     int32_t k;
     int32_t same_counts; /* 1: every cluster has as many members as in the previous iteration (labels MAY be equal) */
+    int32_t reloc_ties;  /* relocation events in which two DIFFERENT samples tied (equal float32 distance) at the selection
+                            cut: scikit-learn keeps whichever numpy.argpartition's introselect leaves there
+                            (_k_means_common.pyx:186-187), this library the larger value -- the fits may part ways */
+    int32_t reloc_multi; /* relocation events with more than one empty cluster: which far sample goes to which empty cluster
+                            is the order numpy.argpartition leaves (implementation defined); here: descending distance */
 } nnc_kmeans_status;
 
 int32_t nnc_fix_shift(float absmax, int64_t n_total);
@@ -188,6 +195,12 @@ size_t nnc_kmeans_workspace_bytes(int32_t k);
 /* centers_init_dev: k float32, un-centred (the reference's `space`).  Resets the state. */
 int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
                     void *stream);
+/* Replaces the current centres by centers_dev[k] (centred != 0: values with x_mean already subtracted, taken as they
+ * are; else un-centred, x_mean is subtracted in float32 as KMeans.fit does with `init`, _kmeans.py:1484), clears done /
+ * paused and rebuilds the search tables; the iteration count stays.  For warm starts, for stepping through a recorded
+ * trajectory one iteration at a time (tests against the reference's per-iteration fixtures) and for writing back
+ * fine-tuned centroids (nnc_centroid_grad_f32). */
+int nnc_kmeans_set_centers(void *ws, const nnc_kmeans_params *p, const float *centers_dev, int centred, void *stream);
 int nnc_kmeans_accumulate(const float *x, void *ws, const nnc_kmeans_params *p, void *stream);
 /* device int64[2*k]: sums (fixed point) then counts, indexed by centroid; valid after
  * nnc_kmeans_accumulate; the caller may all-reduce (SUM) or edit it before finalize. */
@@ -226,7 +239,9 @@ int nnc_kmeans_get_centers(void *ws, int which, int centred, float *out_dev, voi
  *   quant_out  : cluster_centers_[labels_] (un-centred float32 centre values), utility.py:239
  *   dist_out   : (x~ - c~[label])^2 in float32, the distances _relocate_empty_clusters needs
  *   dist_hist4096_dev : with dist_out, also the 4096-bin histogram of (bits(dist) >> 19) & 4095
- *                (zeroed here): the first level of nnc_topm_hist_f32, for free in the same pass */
+ *                (zeroed here): the first level of nnc_topm_hist_f32, for free in the same pass
+ * Any alignment works; the 16-byte-per-lane form is taken when x, quant_out and dist_out are 16-byte aligned and
+ * labels_out is aligned to 4 * label_bytes. */
 int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_params *p, int which, void *labels_out,
                       int label_bytes, float *quant_out, float *dist_out, int64_t *dist_hist4096_dev, void *stream);
 
@@ -248,7 +263,9 @@ int nnc_topm_compact_f32(const float *d, const float *x, int64_t n, uint32_t thr
 /* The relocation edits themselves (_k_means_common.pyx:197-211), as additive changes to the
  * per-cluster sums/counts in nnc_kmeans_partials(): keys_sorted_dev = the selected samples' keys
  * in descending order (nkeys of them, the same on every rank); the i-th empty cluster takes the
- * i-th sample, whose value travels in the key and whose current cluster is re-derived exactly. */
+ * i-th sample, whose value travels in the key and whose current cluster is re-derived exactly.
+ * Pass one key more than there are empty clusters when there is one: the runner-up shows whether
+ * the cut fell between two different samples of equal distance (status.reloc_ties). */
 int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream);
 
 /* The same selection without a pass over the whole vector, for a VALUE-SORTED x (nnc_sort_f32),
@@ -261,7 +278,8 @@ int nnc_kmeans_relocate(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys,
  *     {n_cand, n_windows, bad, window} into meta_dev[4].
  *   The caller runs nnc_kmeans_assign on cand_x_dev (n = cap, dist_out) for the exact distances.
  *   nnc_kmeans_relocate_checked: picks the n_empty largest keys (distance bits << 32 | ordered
- *     value bits) among the n_cand candidates into keys_out_dev[n_empty] (descending), proves
+ *     value bits) among the n_cand candidates into keys_out_dev[n_empty + 1] (descending; the last
+ *     entry is the runner-up, 0 if there is none), proves
  *     that no sample outside the windows can be among the n_empty farthest (every stretch
  *     between windows lies outside the zones of all centres but one and ends strictly below the
  *     n_empty-th key's distance) and then relocates as nnc_kmeans_relocate.  If the proof fails
@@ -292,8 +310,6 @@ int nnc_kmeans_reloc_select_local(const float *x_sorted, void *ws, const nnc_kme
                                   void *scratch_dev, size_t scratch_bytes, int64_t *keys_out_dev, void *stream);
 int32_t *nnc_kmeans_reloc_flag(void *ws);
 int nnc_kmeans_relocate_if_proven(void *ws, const int64_t *keys_sorted_dev, int32_t nkeys, void *stream);
-/* diagnostics: why the last proof failed (0 = it held); synchronous */
-int nnc_debug_reloc_fail(void *ws, int32_t *host_out);
 /* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence
  * test, _kmeans.py:717); nnc_kmeans_set_done_if sets done = done_code when *flag_dev != 0. */
 int nnc_labels_equal(const void *a, const void *b, int64_t n, int label_bytes, int32_t *flag_dev, void *stream);
@@ -312,14 +328,20 @@ int nnc_profile_begin(int32_t max_launches);
  * machine had stopped return at once and show up as very short entries. */
 int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out);
 
-/* Timing experiments only (bench tooling): a != 0 selects an ablated build of the Lloyd streaming
- * kernel whose RESULTS ARE WRONG (1: no LDS atomics, 2: no table lookups, 3: neither). */
+#ifdef NNC_DIAG
+/* Diagnostics: exported only by a library built with -DNNC_DIAG (libnnc_hip_diag.so, tools/); the product library has
+ * no process-global switches.
+ * nnc_debug_set_ablation: a != 0 selects an ablated build of the Lloyd streaming kernel whose RESULTS ARE WRONG (1: no
+ *   LDS atomics, 2: no table lookups, 3: neither).
+ * nnc_debug_set_trace: if buf_dev != NULL every workgroup of the Lloyd streaming kernel stores four 100 MHz timestamps
+ *   {start, loop start, loop end, end} at buf_dev[4*blockIdx].
+ * nnc_debug_clock: out_dev[2b] = shader clock in GHz seen by workgroup b over a spin loop, out_dev[2b+1] = its length in us.
+ * nnc_debug_reloc_fail: why the last windowed-relocation proof failed (0 = it held); synchronous. */
 int nnc_debug_set_ablation(int a);
-/* Diagnostic: if buf_dev != NULL every workgroup of the Lloyd streaming kernel stores four 100 MHz
- * timestamps {start, loop start, loop end, end} at buf_dev[4*blockIdx]. */
 int nnc_debug_set_trace(unsigned long long *buf_dev);
-/* Diagnostic: out_dev[2b] = shader clock in GHz seen by workgroup b over a spin loop, out_dev[2b+1] = its length in us. */
 int nnc_debug_clock(int blocks, int iters, float *out_dev, void *stream);
+int nnc_debug_reloc_fail(void *ws, int32_t *host_out);
+#endif
 
 /* Huffman code length per centroid index from the index histogram (HOST function, host
  * pointers).  The reference names Huffman coding (README.md:9) but never implements it; the

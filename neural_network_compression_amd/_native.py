@@ -45,6 +45,7 @@ class KMeansStatus(ctypes.Structure):
     _fields_ = [
         ("iter", c_i32), ("done", c_i32), ("paused", c_i32), ("n_empty", c_i32),
         ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("same_counts", c_i32),
+        ("reloc_ties", c_i32), ("reloc_multi", c_i32),
     ]
 
 
@@ -72,6 +73,7 @@ SIGNATURES = {
     "nnc_fix_shift": (c_i32, [c_f32, c_i64]),
     "nnc_kmeans_workspace_bytes": (c_size, [c_i32]),
     "nnc_kmeans_init": (c_int, [c_void_p, c_size, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
+    "nnc_kmeans_set_centers": (c_int, [c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_int, c_void_p]),
     "nnc_kmeans_accumulate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_void_p]),
     "nnc_kmeans_partials": (c_void_p, [c_void_p]),
     "nnc_kmeans_finalize": (c_int, [c_void_p, c_int, c_void_p]),
@@ -94,16 +96,20 @@ SIGNATURES = {
     "nnc_kmeans_reloc_select_local": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p, c_void_p]),
     "nnc_kmeans_reloc_flag": (c_void_p, [c_void_p]),
     "nnc_kmeans_relocate_if_proven": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
-    "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
     "nnc_profile_begin": (c_int, [c_i32]),
     "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), c_i64, ctypes.POINTER(c_i64)]),
+    "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+}
+
+# exported only by the diagnostics build (NNC_DIAG=1: libnnc_hip_diag.so, see build.py); bound when present
+DIAG_SIGNATURES = {
     "nnc_debug_set_ablation": (c_int, [c_int]),
     "nnc_debug_set_trace": (c_int, [c_void_p]),
     "nnc_debug_clock": (c_int, [c_int, c_int, c_void_p, c_void_p]),
-    "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
 }
 
 _lib = None
@@ -135,6 +141,11 @@ def load():
             raise NativeLibraryError(f"{path} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        fn = getattr(L, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = L
     return L
 

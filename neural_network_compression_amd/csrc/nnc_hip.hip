@@ -12,6 +12,8 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -52,17 +54,27 @@ int nnc_set_error_(int code, const char *msg) { return fail(code, msg ? msg : ""
 extern "C" int nnc_version(void) { return NNC_VERSION; }
 extern "C" const char *nnc_last_error(void) { return g_err.c_str(); }
 
-static int g_cu_count = 0;
+// Per-device caches (a process may drive several GPUs, from several host threads): indexed by the current device, the
+// entries only ever go from "unknown" to the one value every thread would compute, so plain atomics suffice.
+#define NNC_MAX_DEVICES 64
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NNC_MAX_DEVICES) dev = 0;
+    return dev;
+}
+static std::atomic<int> g_cu_count[NNC_MAX_DEVICES];
 static int cu_count()
 {
-    if (g_cu_count == 0) {
-        int dev = 0;
+    const int dev = current_device();
+    int c = g_cu_count[dev].load(std::memory_order_relaxed);
+    if (c == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            g_cu_count = prop.multiProcessorCount;
-        if (g_cu_count <= 0) g_cu_count = 256;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        if (c <= 0) c = 256;
+        g_cu_count[dev].store(c, std::memory_order_relaxed);
     }
-    return g_cu_count;
+    return c;
 }
 
 extern "C" int nnc_device_info(char *arch_out, size_t arch_len, int *cu_count_out)
@@ -788,8 +800,17 @@ static size_t km_lds_bytes(int k, int glog2, int rlog2, bool accumulate)
 
 // ---- the streaming kernel ------------------------------------------------------------
 // MODE 0: E-step + accumulate (Lloyd iteration).  MODE 1: E-step + write labels / values / distances.
-__device__ unsigned long long *g_fin_trace = nullptr; // diagnostic: phase timestamps of k_finalize (thread 0)
-__device__ unsigned long long *g_km_trace = nullptr; // diagnostic: per-workgroup {t_start, t_loop, t_epilogue, t_end} in 100 MHz ticks
+// Diagnostics (phase timestamps, ablated kernels, tuning knobs read from the environment) exist only in a build with
+// -DNNC_DIAG (NNC_DIAG=1 python -m neural_network_compression_amd.build -> libnnc_hip_diag.so, used by tools/).
+#ifdef NNC_DIAG
+__device__ unsigned long long *g_fin_trace = nullptr; // phase timestamps of k_finalize (thread 0)
+__device__ unsigned long long *g_km_trace = nullptr; // per-workgroup {t_start, t_loop, t_epilogue, t_end} in 100 MHz ticks
+#define NNC_KM_TRACE_PTR g_km_trace
+#define NNC_FIN_TRACE_PTR g_fin_trace
+#else
+#define NNC_KM_TRACE_PTR ((unsigned long long *)nullptr)
+#define NNC_FIN_TRACE_PTR ((unsigned long long *)nullptr)
+#endif
 
 struct KmCtx {
     const uint16_t *cell_s;  // u16[G]: p_lo | (min(cnt-1, 31) << 11)
@@ -1004,7 +1025,7 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
 {
     extern __shared__ __align__(16) unsigned char smem[];
     if (MODE == 1 && n_dev) n = *n_dev; // label mode only: the real length lives on the device (the grid was sized for a bound)
-    unsigned long long *trace = (MODE == 0) ? g_km_trace : nullptr;
+    unsigned long long *trace = (MODE == 0) ? NNC_KM_TRACE_PTR : nullptr;
     unsigned long long tr0 = 0, tr1 = 0, tr2 = 0;
     if (trace) tr0 = __builtin_amdgcn_s_memrealtime();
 
@@ -1260,7 +1281,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     __shared__ double wave_a[NT / 64], wave_b[NT / 64];
 
     const int tid = threadIdx.x;
-    unsigned long long *ftr = g_fin_trace;
+    unsigned long long *ftr = NNC_FIN_TRACE_PTR;
 #define FSTAMP(i) do { if (ftr && tid == 0) ftr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     FSTAMP(0);
     if (tid == 0) ws->cells_pending = 0;
@@ -1747,6 +1768,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
         ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
+        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0;
         ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0; ws->cells_pending = 0;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
@@ -1780,13 +1802,40 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     return km_launch_finalize(w, p, FIN_INIT, 0, stream);
 }
 
+// Replace the current centres (warm start, stepping through a recorded trajectory, centroid fine-tuning): clears done /
+// paused, keeps the iteration count, rebuilds the search tables.
+__global__ __launch_bounds__(KM_THREADS) void k_km_set_centers(KmWs *ws, const float *__restrict__ centers, int centred)
+{
+    const int tid = threadIdx.x;
+    const int k = ws->p.k, cur = ws->cur;
+    const float mean = ws->p.x_mean;
+    for (int j = tid; j < k; j += KM_THREADS) ws->c[cur][j] = centred ? centers[j] : (centers[j] - mean);
+    for (int j = tid; j < NNC_KMAX; j += KM_THREADS) ws->prev_counts[j] = -1;
+    if (tid == 0) { ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0; ws->st.same_counts = 0; ws->reloc_fail = 0; }
+}
+
+extern "C" int nnc_kmeans_set_centers(void *ws, const nnc_kmeans_params *p, const float *centers_dev, int centred, void *stream)
+{
+    int rc = km_check(ws, p, "nnc_kmeans_set_centers");
+    if (rc) return rc;
+    if (!centers_dev) return fail(NNC_EINVAL, "nnc_kmeans_set_centers: null centers");
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
+    hipLaunchKernelGGL(k_km_set_centers, dim3(1), dim3(KM_THREADS), 0, S(stream), w, centers_dev, centred);
+    LAUNCHCHK("k_km_set_centers");
+    return km_launch_finalize(w, p, FIN_INIT, 0, stream);
+}
+
 static int km_grid(int64_t n, size_t lds_bytes)
 {
     int64_t blocks = ((n + 7) / 8 + KM_THREADS - 1) / KM_THREADS;
     if (blocks < 1) blocks = 1;
     int per_cu = (lds_bytes + 1024 <= 80 * 1024) ? 2 : 1; // two 1024-thread workgroups fit a CU if LDS allows
-    static int mult_q = -1; // tuning knob: workgroups per resident slot, in quarters (NNC_KM_GRID_QUARTERS)
-    if (mult_q < 0) { const char *e = getenv("NNC_KM_GRID_QUARTERS"); mult_q = e ? atoi(e) : 4; if (mult_q < 1) mult_q = 4; }
+    int mult_q = 4; // workgroups per resident slot, in quarters
+#ifdef NNC_DIAG
+    static int mult_env = -1; // tuning knob (NNC_KM_GRID_QUARTERS)
+    if (mult_env < 0) { const char *e = getenv("NNC_KM_GRID_QUARTERS"); mult_env = e ? atoi(e) : 4; if (mult_env < 1) mult_env = 4; }
+    mult_q = mult_env;
+#endif
     return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu * mult_q / 4);
 }
 
@@ -1796,14 +1845,16 @@ static int km_grid(int64_t n, size_t lds_bytes)
 // on to report the kernel's average duration over the timed region.
 // --------------------------------------------------------------------------------------
 struct ProfPair { hipEvent_t a, b; };
+static std::mutex g_prof_mu;            // the pool is shared by every calling thread
 static std::vector<ProfPair> g_prof_pool;
 static size_t g_prof_used = 0;
-static bool g_prof_on = false;
+static std::atomic<bool> g_prof_on{false};
 static int64_t g_prof_skipped = 0;
 
 extern "C" int nnc_profile_begin(int32_t max_launches)
 {
     if (max_launches < 1) return fail(NNC_EINVAL, "nnc_profile_begin: max_launches < 1");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     while ((int64_t)g_prof_pool.size() < max_launches) {
         ProfPair pp;
         HIPCHK(hipEventCreate(&pp.a));
@@ -1821,6 +1872,7 @@ extern "C" int nnc_profile_begin(int32_t max_launches)
 extern "C" int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out)
 {
     g_prof_on = false;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     int64_t cnt = 0;
     for (size_t i = 0; i < g_prof_used; i++) {
         HIPCHK(hipEventSynchronize(g_prof_pool[i].b));
@@ -1834,6 +1886,7 @@ extern "C" int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out)
     return NNC_OK;
 }
 
+#ifdef NNC_DIAG
 // diagnostic: shader clock = d(s_memtime) / d(s_memrealtime) * 100 MHz over a VALU spin loop
 __global__ void k_debug_clock(int iters, float *out)
 {
@@ -1868,6 +1921,9 @@ extern "C" int nnc_debug_clock(int blocks, int iters, float *out_dev, void *stre
 static int g_ablation = 0;
 static int g_deal = []() { const char *e = getenv("NNC_KM_DEAL"); return e ? atoi(e) : 1; }(); // tuning knob: 0 = contiguous ranges only
 extern "C" int nnc_debug_set_ablation(int a) { g_ablation = a; return NNC_OK; }
+#else
+static const int g_ablation = 0, g_deal = 1;
+#endif
 
 static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream, int which = 0)
 {
@@ -1877,43 +1933,50 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     int grid = km_grid(p->n, lds);
     if (p->n == 0) return NNC_OK;
-    const bool prof = g_prof_on && g_prof_used < g_prof_pool.size();
-    if (g_prof_on && !prof) g_prof_skipped++;
     // hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end (not at the
     // command processor's arrival), so the difference is the launch's execution time
-    hipEvent_t ev_a = prof ? g_prof_pool[g_prof_used].a : nullptr;
-    hipEvent_t ev_b = prof ? g_prof_pool[g_prof_used].b : nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (g_prof_on.load(std::memory_order_relaxed)) {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (g_prof_on && g_prof_used < g_prof_pool.size()) { ev_a = g_prof_pool[g_prof_used].a; ev_b = g_prof_pool[g_prof_used].b; g_prof_used++; }
+        else g_prof_skipped++;
+    }
 #define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, which, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr)
-    if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
+    if (false) {}
+#ifdef NNC_DIAG
+    else if (vec && g_ablation == 1) KM_LAUNCH_ACC(true, uint8_t, 1);
     else if (vec && g_ablation == 2) KM_LAUNCH_ACC(true, uint8_t, 2);
     else if (vec && g_ablation == 3) KM_LAUNCH_ACC(true, uint8_t, 3);
+#endif
     else if (vec && g_deal && (grid & 1) == 0 && (p->n / (4 * KM_THREADS)) >= 4 * (int64_t)grid) KM_LAUNCH_ACC(true, uint8_t, 0, true);
     else if (vec) KM_LAUNCH_ACC(true, uint8_t);
     else KM_LAUNCH_ACC(false, uint8_t);
 #undef KM_LAUNCH_ACC
     LAUNCHCHK("k_assign<accumulate>");
-    if (prof) g_prof_used++;
     return NNC_OK;
 }
 
-static bool g_lds_attr_set = false;
+static std::atomic<int> g_lds_attr_set[NNC_MAX_DEVICES]; // function attributes are per device
 static int km_set_lds_attr()
 {
-    if (g_lds_attr_set) return NNC_OK;
+    const int dev = current_device();
+    if (g_lds_attr_set[dev].load(std::memory_order_acquire)) return NNC_OK;
     const int maxlds = 160 * 1024;
 #define SETATTR(fn) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&fn), hipFuncAttributeMaxDynamicSharedMemorySize, maxlds))
     SETATTR((k_assign<0, true, uint8_t>));
     SETATTR((k_assign<0, true, uint8_t, 0, true>));
+#ifdef NNC_DIAG
     SETATTR((k_assign<0, true, uint8_t, 1>));
     SETATTR((k_assign<0, true, uint8_t, 2>));
     SETATTR((k_assign<0, true, uint8_t, 3>));
+#endif
     SETATTR((k_assign<0, false, uint8_t>));
     SETATTR((k_assign<1, true, uint8_t>));
     SETATTR((k_assign<1, false, uint8_t>));
     SETATTR((k_assign<1, true, uint16_t>));
     SETATTR((k_assign<1, false, uint16_t>));
 #undef SETATTR
-    g_lds_attr_set = true;
+    g_lds_attr_set[dev].store(1, std::memory_order_release);
     return NNC_OK;
 }
 
@@ -2080,7 +2143,9 @@ static int km_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int 
     km_defaults(&p, &glog2, &rlog2);
     if (dist_hist4096_dev && !dist_out) return fail(NNC_EINVAL, "nnc_kmeans_assign: the distance histogram needs dist_out");
     size_t lds = km_lds_bytes(p.k, glog2, rlog2, false) + (dist_hist4096_dev ? 4096 * sizeof(unsigned) : 0);
-    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    // the vector form stores labels 4 at a time (4 / 8 bytes) and values / distances as float4: every output counts
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(quant_out) | reinterpret_cast<uintptr_t>(dist_out)) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(labels_out) & (size_t)(4 * label_bytes - 1)) == 0;
     int grid = km_grid(p.n, lds);
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     unsigned long long *dh = reinterpret_cast<unsigned long long *>(dist_hist4096_dev);
@@ -2244,6 +2309,12 @@ __device__ void km_relocate_apply(KmWs *__restrict__ ws, const long long *__rest
     const int k = ws->p.k;
     const int m = n_empty < nkeys ? n_empty : nkeys;
     if (m == 0 || (keys[0] >> 32) == 0) return;
+    if (tid == 0) {
+        // what scikit-learn leaves to numpy.argpartition: the pairing when several clusters are empty, and WHICH samples
+        // are taken when two different ones tie at the cut (the runner-up key, if the caller passed it, tells)
+        if (m > 1) ws->st.reloc_multi += 1;
+        if (nkeys > m && keys[m] != 0 && (keys[m] >> 32) == (keys[m - 1] >> 32) && keys[m] != keys[m - 1]) ws->st.reloc_ties += 1; // (0: padding)
+    }
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
     auto edit = [&](int i, float xc, int old) {
@@ -2538,7 +2609,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     __shared__ KmRelocLds rl;
     __shared__ double zl_s[NNC_KMAX];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    unsigned long long *strc = g_km_trace; // diagnostics: phase stamps behind the workgroup records
+    unsigned long long *strc = NNC_KM_TRACE_PTR; // diagnostics: phase stamps behind the workgroup records
 #define RSTAMP(i) do { if (strc && tid == 0) strc[3000 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RSTAMP(0);
     const int n_cand = meta[0];
@@ -2693,7 +2764,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
                 }
         }
         __syncthreads();
-        for (int r = tid; r < n_empty; r += KM_THREADS) keys_out[r] = (long long)surv[r];
+        // (one key more than needed, 0 if there is none: the runner-up shows a tie at the cut, see km_relocate_apply)
+        for (int r = tid; r <= n_empty; r += KM_THREADS) keys_out[r] = (r < m) ? (long long)surv[r] : 0ll;
     }
     __syncthreads();
     RSTAMP(3);
@@ -2750,12 +2822,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     if (tid == 0) ws->reloc_fail = any_bad;
     if (any_bad || !do_relocate) return; // (sharded vector: the ranks first exchange their keys and their verdicts)
     __threadfence_block();
-    km_relocate_apply(ws, keys_out, n_empty, n_empty_ws, &rl);
+    km_relocate_apply(ws, keys_out, min(m, n_empty + 1), n_empty_ws, &rl);
     RSTAMP(5);
 #undef RSTAMP
 }
 
-static bool g_reloc_dist_attr = false;
+static std::atomic<int> g_reloc_dist_attr[NNC_MAX_DEVICES];
 // windows, candidates and their distances (two launches)
 static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window, float *cand_x,
                                  float *cand_d, int64_t cap, void *win_dev, int32_t *meta_dev, unsigned *hist0, void *stream)
@@ -2764,9 +2836,9 @@ static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmea
     km_defaults(p, &glog2, &rlog2);
     const size_t lds = km_lds_bytes(p->k, glog2, rlog2, false) + (NNC_KMAX + 2) * sizeof(int);
     if (lds > 128 * 1024) return fail(NNC_EINVAL, "relocation: search tables too large for the candidate kernel");
-    if (!g_reloc_dist_attr) {
+    if (!g_reloc_dist_attr[current_device()].load(std::memory_order_acquire)) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); // + 16 KB static
-        g_reloc_dist_attr = true;
+        g_reloc_dist_attr[current_device()].store(1, std::memory_order_release);
     }
     hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
                        reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
@@ -2799,12 +2871,14 @@ extern "C" int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, cons
     return NNC_OK;
 }
 
+#ifdef NNC_DIAG
 extern "C" int nnc_debug_reloc_fail(void *ws, int32_t *host_out)
 {
     if (!ws || !host_out) return fail(NNC_EINVAL, "nnc_debug_reloc_fail: null pointer");
     HIPCHK(hipMemcpy(host_out, &reinterpret_cast<KmWs *>(ws)->reloc_fail, sizeof(int32_t), hipMemcpyDeviceToHost));
     return NNC_OK;
 }
+#endif
 
 extern "C" int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, const float *cand_d_dev, const void *win_dev,
                                            const int32_t *meta_dev, int32_t n_empty, int64_t *keys_out_dev, void *stream)

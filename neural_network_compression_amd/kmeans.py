@@ -265,16 +265,26 @@ class DeviceKMeans:
         return self._ticket
 
     def wait(self, ticket: int) -> nat.KMeansStatus:
+        """Polls the ticket word the device writes behind the status block (pinned, fine-grained coherent host memory:
+        torch's pinned allocations are, unless HIP_HOST_COHERENT=0).  A short spin (a look-in normally lands within a
+        few hundred microseconds), then the GIL is released between polls so that other host threads run, and after
+        20 ms the stream is synchronised once: that makes the write visible even through a non-coherent mapping and
+        surfaces a device error instead of hanging."""
         t = self._slot_ticket[ticket & 1]
-        spins = 0
+        spins, synced, t0 = 0, False, 0.0
         while t.value != ticket:
             spins += 1
-            if spins == 1:
+            if spins == 2000:
                 t0 = time.monotonic()
-            elif spins & 0xFFFFF == 0 and time.monotonic() - t0 > 60.0:   # a dead stream must not hang the host
-                torch.cuda.current_stream(self.dev).synchronize()          # surfaces the device error, if any
-                if t.value != ticket:
-                    raise RuntimeError("k-means status never arrived")
+            elif spins > 2000:
+                time.sleep(0)   # yield: a second rank thread or a data loader must not starve
+                if spins & 0x3F == 0:
+                    el = time.monotonic() - t0
+                    if el > 0.02 and not synced:
+                        torch.cuda.current_stream(self.dev).synchronize()
+                        synced = True
+                    elif el > 60.0:
+                        raise RuntimeError("k-means status never arrived")
         return self._slot_status[ticket & 1]
 
     def status(self) -> nat.KMeansStatus:
@@ -333,14 +343,15 @@ class DeviceKMeans:
     TOPM_CAP = 1 << 16
 
     def _top_keys(self, d: torch.Tensor, x: torch.Tensor, m: int, hist0: torch.Tensor | None = None) -> torch.Tensor:
-        """Keys of the m samples farthest from their own centre (this shard), descending.  A key is
+        """Keys of the m + 1 samples farthest from their own centre (this shard), descending (the runner-up lets the
+        relocation kernel see a tie at the cut; fewer if the shard is shorter).  A key is
         (float32 bits of d) << 32 | order-preserving bits of x: descending keys = descending
         distance, equal distances by descending value; samples equal in both are interchangeable,
         so the outcome does not depend on sample order or on how the vector is sharded.
         Histogram of the distance bits -> threshold -> compaction of the survivors (HIP kernels,
         refined inside the cut bin while it is crowded) -> sort of the few survivors."""
         n = d.numel()
-        m = min(m, n)
+        m = min(m + 1, n)
         if m == 0:
             return torch.empty(0, dtype=torch.int64, device=self.dev)
         hist = hist0 if hist0 is not None else torch.empty(4096, dtype=torch.int64, device=self.dev)
@@ -393,15 +404,15 @@ class DeviceKMeans:
             return True
         import torch.distributed as dist
 
-        keys = torch.empty(n_empty, dtype=torch.int64, device=self.dev)
+        keys = torch.empty(n_empty + 1, dtype=torch.int64, device=self.dev)
         nat.check(self.L.nnc_kmeans_reloc_select_local(self.x_iter.data_ptr(), ws, ctypes.byref(self.p), n_empty,
                                                        self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(),
                                                        keys.data_ptr(), self.stream))
         dist.all_reduce(self._reloc_flag, op=dist.ReduceOp.MAX, group=self.group)   # any rank unproven -> nobody relocates
         bufs = [torch.empty_like(keys) for _ in range(dist.get_world_size(self.group))]
         dist.all_gather(bufs, keys, group=self.group)
-        merged = torch.sort(torch.cat(bufs), descending=True).values[:n_empty].contiguous()
-        nat.check(self.L.nnc_kmeans_relocate_if_proven(ws, merged.data_ptr(), n_empty, self.stream))
+        merged = torch.sort(torch.cat(bufs), descending=True).values[:n_empty + 1].contiguous()
+        nat.check(self.L.nnc_kmeans_relocate_if_proven(ws, merged.data_ptr(), n_empty + 1, self.stream))
         nat.check(self.L.nnc_kmeans_finalize(ws, 1, self.stream))
         return True
 
@@ -447,12 +458,12 @@ class DeviceKMeans:
             import torch.distributed as dist
 
             world = dist.get_world_size(self.group)
-            pad = torch.full((n_empty,), -1, dtype=torch.int64, device=self.dev)
+            pad = torch.full((n_empty + 1,), -1, dtype=torch.int64, device=self.dev)
             pad[: keys.numel()] = keys
             bufs = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(bufs, pad, group=self.group)
             allk = torch.sort(torch.cat(bufs), descending=True).values
-            keys = allk[: min(n_empty, self.n_total)].contiguous()
+            keys = allk[: min(n_empty + 1, self.n_total)].contiguous()
         nat.check(self.L.nnc_kmeans_relocate(self.ws.data_ptr(), keys.data_ptr(), int(keys.numel()), self.stream))
         nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 1, self.stream))
         if flag is not None:
@@ -512,4 +523,8 @@ class DeviceKMeans:
         model = QuantizedModel(centers, lab, n_iter, self.n_relocations, stop)
         model.counts_device_ = counts
         model.n_reloc_windowed_ = self.n_reloc_windowed   # relocation events settled without a pass over the vector
+        # what scikit-learn leaves to numpy.argpartition (include/nnc.h, nnc_kmeans_status): events in which two different
+        # samples tied at the selection cut (the fits may part ways there), events with more than one empty cluster
+        model.reloc_tie_ = int(st.reloc_ties)
+        model.n_reloc_multi_ = int(st.reloc_multi)
         return model, vals

@@ -99,9 +99,13 @@ def initial_centroids(x: torch.Tensor, bits: int, mode: str, cdfs=None, group=No
     if mode == "forgy":
         import torch.distributed as dist
 
-        # same global index draw on every rank; each rank contributes the samples it owns
+        # every rank draws (so that every rank's global RNG advances as the reference's would), but only rank 0's draw
+        # counts: the ranks' RNG states are not guaranteed to agree; each rank contributes the samples it owns
         n_total = sharding.total_count(x.numel(), x.device, group) if n_total is None else n_total
         idx = np.random.randint(0, n_total, size=2 ** bits)
+        idx_t = torch.from_numpy(np.ascontiguousarray(idx, dtype=np.int64)).to(x.device)
+        dist.broadcast(idx_t, src=dist.get_global_rank(group, 0), group=group)
+        idx = idx_t.cpu().numpy()
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         lo, hi = sharding.shard_bounds(n_total, world, rank)
         vals = torch.zeros(idx.size, dtype=torch.float32, device=x.device)

@@ -294,7 +294,7 @@ def estep(xc: np.ndarray, c: np.ndarray) -> np.ndarray:
     return labels
 
 
-def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True):
+def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True, reloc=None, info=None):
     """One sklearn lloyd_iter_chunked_dense(update_centers=True) on centred data.
     Returns (labels, centers_new float32, counts, shift float32[K], n_empty)."""
     L = lib()
@@ -314,7 +314,16 @@ def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True):
     if n_empty:
         d = np.empty(xc.size, dtype=np.float32)
         L.orc_dist_own_f32(_p(xc, _f32p), xc.size, _p(c_old, _f32p), _p(labels, _i32p), _p(d, _f32p))
-        if accum == "A":
+        if reloc is None:
+            reloc = "argpartition" if accum == "A" else "descending"
+        if info is not None:
+            # an exact tie at the selection cut: the samples sklearn takes then depend on numpy's introselect
+            ds = np.sort(d)
+            info["reloc_events"] = info.get("reloc_events", 0) + 1
+            info["reloc_multi"] = info.get("reloc_multi", 0) + (n_empty > 1)
+            if n_empty < d.size and ds[-n_empty] == ds[-n_empty - 1] and ds[-n_empty] != 0:
+                info["reloc_ties"] = info.get("reloc_ties", 0) + 1
+        if reloc == "argpartition":
             # scikit-learn: whatever order numpy.argpartition leaves the top n_empty indices in
             far = np.argpartition(d, -n_empty)[: -n_empty - 1 : -1].astype(np.int32)
         else:
@@ -363,7 +372,7 @@ def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True):
     return labels, cen, wic.copy(), shift, n_empty
 
 
-def kmeans_lloyd(x, init, accum="A", max_iter=300, tol=1e-4, n_total=None, keep_trace=False):
+def kmeans_lloyd(x, init, accum="A", max_iter=300, tol=1e-4, n_total=None, keep_trace=False, reloc=None):
     """KMeans(n_clusters=K, init=init[:,None], n_init=1, algorithm='full').fit(x[:,None])
     (utility.py:237-238) -> KMeansResult."""
     x = _f32c(x).ravel()
@@ -382,9 +391,10 @@ def kmeans_lloyd(x, init, accum="A", max_iter=300, tol=1e-4, n_total=None, keep_
     labels_old = np.full(n, -1, dtype=np.int32)
     strict = False
     trace = [] if keep_trace else None
+    info = {}
     n_iter = 0
     for i in range(max_iter):
-        labels, centers_new, counts, shift, n_empty = lloyd_iter(xc, centers, accum, S)
+        labels, centers_new, counts, shift, n_empty = lloyd_iter(xc, centers, accum, S, reloc=reloc, info=info)
         centers = centers_new
         n_iter = i + 1
         tot = np.float32((shift ** 2).sum())
@@ -406,16 +416,17 @@ def kmeans_lloyd(x, init, accum="A", max_iter=300, tol=1e-4, n_total=None, keep_
     res.x_mean_ = x_mean
     res.fix_shift_ = S
     res.centers_centred_ = centers
+    res.reloc_info_ = info
     return res
 
 
-def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, accum="A"):
+def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, accum="A", reloc=None):
     """utility.py:172-240 for the three explicit-init modes."""
     if np.prod(layer_weight.shape) < (2 ** bits) + 1:
         print("not enough bits:", np.prod(layer_weight.shape), " vs ", 2 ** bits)
         return layer_weight, None
     space = init_space(layer_weight, bits, mode, cdfs)
-    km = kmeans_lloyd(layer_weight.reshape(-1), space, accum=accum)
+    km = kmeans_lloyd(layer_weight.reshape(-1), space, accum=accum, reloc=reloc)
     km.init_space_ = np.asarray(space)
     ris = km.cluster_centers_[km.labels_].reshape(layer_weight.shape)
     return ris, km

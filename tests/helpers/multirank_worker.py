@@ -25,7 +25,7 @@ def main():
     lo, hi = sharding.shard_bounds(n_total, world, rank)
     w = synth.weights((n_total,), seed)
     if mode == "forgy":
-        np.random.seed(1234)
+        np.random.seed(1234 + 17 * rank)   # only rank 0's global RNG state decides the draw (it is broadcast)
     x = torch.from_numpy(w[lo:hi].copy()).cuda()
     res = pipeline.compress_layer(x, q=q if q >= 0 else None, bits=bits, mode=mode, group=group, huffman=True)
     labels = res.model.labels_

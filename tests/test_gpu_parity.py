@@ -254,24 +254,131 @@ def test_fit_matches_oracle_mode_b_bit_exact(nnc, gold, key):
     assert np.array_equal(q, ob.cluster_centers_[ob.labels_].reshape(w.shape)), key
 
 
-@pytest.mark.parametrize("key", GOLD_FITS)
+# ------------------------------------------------------------------ against the reference's own outputs
+# The reference (scikit-learn, one thread) keeps float32 running sums in sample order; the device keeps exact
+# integer sums (order independent).  Every other step is the same arithmetic, so per key the
+# two fits take the SAME number of iterations and differ only by scikit-learn's summation error.  The table is the
+# contract: key -> (bound on max |centre - golden centre| / max |golden centre|,
+#                   bound on sum |bincount - golden bincount|,
+#                   bound on the number of differing labels where the goldens hold the label vector, else None).
+# A bound of 0 means exact; label vectors are also compared by SHA-256 wherever the histogram bound is 0.
+# (north_star: "bit-exact indices, 1e-6 relative centroid values": met by the rows that say 1e-06 / 0; the others
+# carry scikit-learn's own float32 accumulation error, measured with the oracle's mode A <-> mode B gap.)
+REF_BOUNDS = {
+    "quant/cfg1/l300.dense1.w/density2": (3.3e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/density2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/density4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/density5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/forgy2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/forgy4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/forgy5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/linear2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/linear4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.b/linear5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense1.w/density2": (3.3e-06, 0, None),
+    "quant/cfg2/l300.dense1.w/density4": (8e-06, 2, None),
+    "quant/cfg2/l300.dense1.w/density5": (4.4e-06, 4, None),
+    "quant/cfg2/l300.dense1.w/forgy2": (3.3e-06, 0, None),
+    "quant/cfg2/l300.dense1.w/forgy4": (1.2e-05, 2, None),
+    "quant/cfg2/l300.dense1.w/forgy5": (1.7e-05, 2, None),
+    "quant/cfg2/l300.dense1.w/linear2": (2e-06, 0, None),
+    "quant/cfg2/l300.dense1.w/linear5": (7.7e-05, 20, None),
+    "quant/cfg2/l300.dense2.b/density2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/density4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/density5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/forgy2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/forgy4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/forgy5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/linear2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/linear4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.b/linear5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/density2": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/density4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/density5": (4e-05, 2, 1),
+    "quant/cfg2/l300.dense2.w/forgy2": (2.1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/forgy4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/forgy5": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/linear2": (1.6e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/linear4": (1e-06, 0, 0),
+    "quant/cfg2/l300.dense2.w/linear5": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.b/density2": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.b/forgy2": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.b/linear2": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/density2": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/density4": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/density5": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/forgy2": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/forgy4": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/forgy5": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/linear2": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/linear4": (1e-06, 0, 0),
+    "quant/cfg2/l300.out.w/linear5": (1e-06, 0, 0),
+    "quant/cfg3/l5.conv1.w/forgy5": (1e-06, 0, 0),
+    "quant/cfg3/l5.conv2.b/forgy5": (1e-06, 0, 0),
+    "quant/cfg3/l5.conv2.w/forgy5": (1e-06, 0, 0),
+    "quant/cfg3/l5.dense1.b/forgy5": (1e-06, 0, 0),
+    "quant/cfg3/l5.dense1.w/forgy5": (1.3e-05, 16, None),
+    "quant/cfg3/l5.out.w/forgy5": (1e-06, 0, 0),
+    "quant/cfg4/flat200k/density8": (0.00043, 40, None),
+    "quant/cfg4/flat200k/forgy8": (0.00014, 146, None),
+    "quant/cfg5/attn_proj768/linear4": (8.1e-06, 8, None),
+    "quant/unpruned50k/density2": (1e-06, 0, None),
+    "quant/unpruned50k/density3": (1.4e-06, 0, None),
+    "quant/unpruned50k/density4": (0.00025, 26, 19),
+    "quant/unpruned50k/density6": (9.1e-05, 8, None),
+    "quant/unpruned50k/forgy2": (1.7e-06, 0, None),
+    "quant/unpruned50k/forgy3": (1.2e-06, 0, None),
+    "quant/unpruned50k/forgy4": (1e-06, 0, 0),
+    "quant/unpruned50k/forgy6": (9.6e-05, 22, None),
+    "quant/unpruned50k/linear2": (1.9e-06, 2, None),
+    "quant/unpruned50k/linear3": (3.7e-05, 4, None),
+    "quant/unpruned50k/linear4": (1e-06, 0, 0),
+    "quant/unpruned50k/linear6": (3.1e-05, 2, None),
+}
+
+# One golden fit lands in a different local optimum, for a reason that is not arithmetic: in iteration 0 two clusters
+# are empty and two different samples (193901, 196141) have exactly the same float32 distance 0.00019625 at the
+# selection cut.  scikit-learn keeps the one numpy.argpartition's introselect leaves there (implementation defined,
+# _k_means_common.pyx:186-187); the device keeps the larger value and REPORTS the tie (model.reloc_tie_).
+REF_TIE_DIVERGENT = {"quant/cfg2/l300.dense1.w/linear4"}
+
+
+def test_reference_bounds_cover_every_golden_fit(gold):
+    fits = {k for k in gold.keys("quant/") if not gold.cases[k]["passthrough"]}
+    assert fits == set(REF_BOUNDS) | REF_TIE_DIVERGENT
+
+
+@pytest.mark.parametrize("key", sorted(REF_BOUNDS))
 def test_fit_against_reference_goldens(nnc, gold, key):
-    """Against the reference's own outputs (float32 running sums, one thread).  Integer
-    results are compared exactly where the trajectory is the same; centre values to the
-    reference's float32 summation error."""
     w, q, km, c = _fit_both(nnc, gold, key)
-    if c["passthrough"]:
-        return
+    err_bound, l1_bound, lab_bound = REF_BOUNDS[key]
+    assert km.reloc_tie_ == 0, key                         # no tie at a relocation cut: the trajectory is the reference's
+    assert km.n_iter_ == c["n_iter"], (key, km.n_iter_, c["n_iter"])
     gc = gold.arr(c["centers"])
-    scale = np.abs(gc).max()
-    if km.n_iter_ == c["n_iter"]:
-        err = np.max(np.abs(km.cluster_centers_.ravel() - gc)) / scale
-        assert err < 2e-3, (key, err)
-        frac = np.mean(np.bincount(km.labels_, minlength=c["K"]) != gold.arr(c["bincount"]))
-        assert frac <= 0.5, (key, frac)
-    else:
-        # the float32-sum trajectory took a different number of steps: still the same optimum?
-        assert abs(km.n_iter_ - c["n_iter"]) <= max(10, c["n_iter"]), (key, km.n_iter_, c["n_iter"])
+    err = np.max(np.abs(km.cluster_centers_.ravel().astype(np.float64) - gc.astype(np.float64))) / np.abs(gc).max()
+    assert err <= err_bound, (key, err)
+    bc = np.bincount(km.labels_, minlength=c["K"]).astype(np.int64)
+    l1 = int(np.abs(bc - gold.arr(c["bincount"])).sum())
+    assert l1 <= l1_bound, (key, l1)
+    if "labels" in c:
+        nd = int((km.labels_ != gold.arr(c["labels"]).astype(np.int32)).sum())
+        assert nd <= lab_bound, (key, nd)
+    if l1_bound == 0 and lab_bound in (0, None):
+        assert sha(km.labels_) == c["labels_sha256"], key   # every centroid index equal to the reference's
+    # the decoded tensor uses the device's own centres
+    assert np.array_equal(q, km.cluster_centers_[km.labels_].reshape(w.shape)), key
+
+
+def test_fit_tie_at_relocation_cut_is_reported(nnc, gold):
+    """The one golden fit that parts ways with scikit-learn does so at a tie the device detects."""
+    (key,) = REF_TIE_DIVERGENT
+    w, q, km, c = _fit_both(nnc, gold, key)
+    assert km.reloc_tie_ >= 1 and km.n_reloc_multi_ >= 1
+    ob = orc.kmeans_lloyd(w.ravel(), gold.arr(c["init"]), accum="B")
+    assert ob.reloc_info_.get("reloc_ties", 0) >= 1                 # the oracle sees the same tie ...
+    assert km.n_iter_ == ob.n_iter_                                  # ... and the device resolves it by its documented rule
+    assert np.array_equal(km.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
+    # every golden fit without a tie reports none (test_fit_against_reference_goldens asserts reloc_tie_ == 0)
 
 
 def test_passthrough_and_errors(nnc, capsys):
@@ -354,9 +461,18 @@ def test_full_size_25m_k256_properties(nnc):
     cen_c = km.centers(which=0, centred=True)
     want = orc.estep((w[sample] - mean).astype(np.float32), cen_c)
     assert np.array_equal(labels[sample], want)
-    # counts add up; each centre is the mean of its members to 1e-6 relative of the data scale
+    # counts add up
     counts = np.bincount(labels, minlength=k)
     assert counts.sum() == n
+    # each centre is the mean of its members to 1e-6 of the data scale: the members of the LAST iteration, i.e. the
+    # E-step on the centres that iteration started from (the returned labels come from one more E-step,
+    # sklearn _kmeans.py:736-748; after a label-equality stop they are the same labels)
+    lab_prev = labels if model.stop_reason_ == "strict" else (km.assign(which=1)[0].to(torch.int32).cpu().numpy() & 0xFFFF)
+    w64 = w.astype(np.float64)
+    cnt = np.bincount(lab_prev, minlength=k)
+    s64 = np.bincount(lab_prev, weights=w64, minlength=k)
+    assert cnt.min() > 0
+    assert np.max(np.abs(centers.astype(np.float64) - s64 / cnt)) <= 1e-6 * float(np.abs(w).max())
 
 
 def test_farthest_selection_rule(nnc):
