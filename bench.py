@@ -5,7 +5,7 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload (BASELINE.json configs[3], "Synthetic 25 M-param fp32 weight vector, K=256"): every
-GPU holds a 25 M-element float32 shard (weak scaling) of one synthetic weight vector
+GPU holds a 25 M-element float32 shard (weak scaling; --scaling strong shards ONE 25 M vector) of one synthetic weight vector
 (neural_network_compression_amd.synth, seed 4000, 0.05 * bell-shaped).  One step = the whole
 per-layer Deep-Compression pass on the data already resident in HBM:
 
@@ -52,7 +52,12 @@ def parse():
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--mode", default="density")
     ap.add_argument("--q", type=float, default=1.0)
-    ap.add_argument("--cpu-sample", type=int, default=16_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=25_000_000, help="weights of the CPU baseline leg (default: the whole 25 M vector, about 20 s)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --n weights per GPU (the driver's scaling run); strong: --n weights in total, sharded over the GPUs "
+                         "(BASELINE configs[3] read literally: one 25 M vector across 8 GPUs)")
+    ap.add_argument("--python-exchange", action="store_true", help="N > 1: issue the per-iteration all-reduce from torch.distributed "
+                                                                   "instead of inside the C library (nnc_kmeans_iterate_sharded)")
     ap.add_argument("--dump-durations", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -92,7 +97,7 @@ def cpu_baseline(args, w_full: np.ndarray):
     dt = time.perf_counter() - t0
     return {
         "value": n / dt, "unit": "weights/s", "cores": threads, "kind": "port",
-        "sample": f"first {n} weights of the same vector, same pipeline (prune q={args.q} sigma, CDF, "
+        "sample": f"{'the whole vector' if n == w_full.size else f'prefix: first {n} weights of the same vector'}, same pipeline (prune q={args.q} sigma, CDF, "
                   f"{args.mode} init, bits={args.bits}, Lloyd to convergence: {n_iter} iterations) in {dt:.2f} s; {impl}",
     }
 
@@ -127,14 +132,17 @@ def main():
     from neural_network_compression_amd import pipeline, sharding, synth
 
     L = nat.load()
-    n_total = args.n * world
+    n_total = args.n * world if args.scaling == "weak" else args.n
     lo, hi = sharding.shard_bounds(n_total, world, rank)
+    comm = None
+    if group is not None and args.backend == "nccl" and not args.python_exchange:
+        comm = sharding.RcclComm(group, dev)   # the library's own RCCL communicator: the exchange is enqueued from C
     w_host = synth.weights((hi - lo,), SEED, start=lo)
     w0 = torch.from_numpy(w_host).to(dev)
 
     def step():
         x = w0.clone()  # prune works in place; the copy is device-to-device, inside the timed region
-        return pipeline.compress_layer(x, q=args.q, bits=args.bits, mode=args.mode, group=group,
+        return pipeline.compress_layer(x, q=args.q, bits=args.bits, mode=args.mode, group=group, comm=comm,
                                        huffman=True, want_values=True)
 
     def barrier():
@@ -190,13 +198,13 @@ def main():
             "unit": "weights/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"configs[3]: synthetic {args.n/1e6:g} M fp32 weights per GPU ({n_total/1e6:g} M total), "
+                "workload": f"configs[3]: synthetic {(hi - lo)/1e6:g} M fp32 weights per GPU ({n_total/1e6:g} M total), "
                             f"prune q={args.q} sigma -> CDF -> {args.mode}-init k-means bits={args.bits} "
                             f"(K={res.model.cluster_centers_.size if res.model else 0}) to convergence -> labels+values -> Huffman lengths",
-                "weights_per_gpu": args.n, "k": int(res.model.cluster_centers_.size) if res.model else 0,
+                "weights_per_gpu": hi - lo, "exchange": ("rccl-in-library" if comm is not None else ("torch.distributed" if world > 1 else None)), "k": int(res.model.cluster_centers_.size) if res.model else 0,
                 "lloyd_iterations": int(n_iter), "stop": res.model.stop_reason_ if res.model else None,
                 "relocations": int(res.model.n_relocations_) if res.model else 0,
                 "parallelism": f"shard{world}" if world > 1 else "single",
@@ -218,6 +226,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, w_host)
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if group is not None:
         import torch.distributed as dist
 

@@ -319,6 +319,47 @@ int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code,
 int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Multi-GPU: the vector is sharded across one process per GPU (contiguous shards starting on multiples of
+ * NNC_CHUNK elements); the exchange per Lloyd iteration is one all-reduce (SUM) of the 2K int64 sums / counts over
+ * RCCL / xGMI, enqueued by the library on the caller's stream between its own kernels.  The reference has no
+ * counterpart (single process; scikit-learn's threads share memory, _k_means_lloyd.pyx:118-152): these entry points
+ * are what BASELINE.json's north_star adds.  RCCL is bound at run time (dlopen), sharing the copy a host framework
+ * has already loaded.
+ * ---------------------------------------------------------------------------------- */
+#define NNC_COMM_ID_BYTES 128
+#define NNC_I64 0
+#define NNC_I32 1
+#define NNC_F32 2
+#define NNC_SUM 0
+#define NNC_MAX 1
+#define NNC_MIN 2
+/* Rank 0 makes the id, the caller carries the NNC_COMM_ID_BYTES bytes to the other ranks (any channel), every rank calls
+ * nnc_comm_init on the thread whose current device is its GPU (blocking rendezvous). */
+int nnc_comm_unique_id(void *id_out, size_t len);
+int nnc_comm_init(void **comm_out, const void *id, size_t len, int32_t rank, int32_t world);
+int nnc_comm_destroy(void *comm);
+int nnc_comm_rank(void *comm);
+int nnc_comm_world(void *comm);
+/* In place on buf_dev; dtype NNC_I64 / NNC_I32 / NNC_F32, op NNC_SUM / NNC_MAX / NNC_MIN. */
+int nnc_comm_allreduce(void *comm, void *buf_dev, int64_t count, int32_t dtype, int32_t op, void *stream);
+/* recv_dev holds world * bytes_per_rank bytes, rank r's block at r * bytes_per_rank. */
+int nnc_comm_allgather(void *comm, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *stream);
+/* nnc_kmeans_iterate for a sharded vector: per iteration nnc_kmeans_accumulate on this rank's shard, the all-reduce of
+ * nnc_kmeans_partials(), nnc_kmeans_finalize -- `iters` of them enqueued back to back, no host round trip in between.
+ * host_mapped / ticket as in nnc_kmeans_iterate_publish (host_mapped may be NULL: no look-in). */
+int nnc_kmeans_iterate_sharded(void *comm, const float *x, void *ws, const nnc_kmeans_params *p, int32_t iters,
+                               void *host_mapped, uint64_t ticket, void *stream);
+/* nnc_kmeans_relocate_windowed for a sharded vector, exchanges included (verdict word: all-reduce MAX; keys: all-gather,
+ * merged on the device); n_empty and the applicability (nnc_kmeans_reloc_window on the SHORTEST shard) must be the same
+ * on every rank.  scratch: nnc_kmeans_reloc_scratch_bytes_sharded(k, window, world) bytes, 256-byte aligned. */
+size_t nnc_kmeans_reloc_scratch_bytes_sharded(int32_t k, int32_t window, int32_t world);
+/* The merge step on its own: `nlists` descending lists of `per` positive int64 keys each (padded with 0 or -1), laid end
+ * to end in lists_dev -> the m largest keys overall, descending, in out_dev[m] (0 where there are fewer). */
+int nnc_merge_keys(const int64_t *lists_dev, int32_t nlists, int32_t per, int64_t *out_dev, int32_t m, void *stream);
+int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
+                                         void *scratch_dev, size_t scratch_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Measurement aid (used by bench.py): HIP events around every launch of the Lloyd streaming
  * kernel, recorded on the stream the kernel is launched on.
  * ---------------------------------------------------------------------------------- */

@@ -99,6 +99,17 @@ SIGNATURES = {
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
+    "nnc_comm_unique_id": (c_int, [c_void_p, c_size]),
+    "nnc_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_size, c_i32, c_i32]),
+    "nnc_comm_destroy": (c_int, [c_void_p]),
+    "nnc_comm_rank": (c_int, [c_void_p]),
+    "nnc_comm_world": (c_int, [c_void_p]),
+    "nnc_comm_allreduce": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p]),
+    "nnc_comm_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "nnc_kmeans_iterate_sharded": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, ctypes.c_uint64, c_void_p]),
+    "nnc_merge_keys": (c_int, [c_void_p, c_i32, c_i32, c_void_p, c_i32, c_void_p]),
+    "nnc_kmeans_reloc_scratch_bytes_sharded": (c_size, [c_i32, c_i32, c_i32]),
+    "nnc_kmeans_relocate_windowed_sharded": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p]),
     "nnc_profile_begin": (c_int, [c_i32]),
     "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), c_i64, ctypes.POINTER(c_i64)]),
     "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -164,13 +164,15 @@ class DeviceKMeans:
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
                  batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
                  reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
-                 n_total: int | None = None, n_min: int | None = None):
+                 n_total: int | None = None, n_min: int | None = None, comm=None):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
         self.L = nat.load()
         self.x = x
         self.group = group
+        # sharding.RcclComm over the same ranks: the per-iteration exchange then runs inside the C library
+        self.comm = comm if group is not None else None
         self.batch = max(1, int(batch))
         self.dev = x.device
         self.stream = ops._stream(x)
@@ -293,6 +295,11 @@ class DeviceKMeans:
 
     def iterate_and_look(self, iters: int) -> nat.KMeansStatus:
         """`iters` iterations and the state behind them.  On one GPU the look-in rides on the batch's last launch."""
+        if self.group is not None and self.comm is not None:
+            self._ticket = _next_ticket()
+            nat.check(self.L.nnc_kmeans_iterate_sharded(self.comm.handle, self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
+                                                        int(iters), self._slot_addr[self._ticket & 1], self._ticket, self.stream))
+            return self.wait(self._ticket)
         if self.group is not None:
             self.iterate(iters)
             return self.status()
@@ -305,6 +312,10 @@ class DeviceKMeans:
         """Enqueue `iters` Lloyd iterations (no host sync)."""
         if self.group is None:
             nat.check(self.L.nnc_kmeans_iterate(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters), self.stream))
+            return
+        if self.comm is not None:
+            nat.check(self.L.nnc_kmeans_iterate_sharded(self.comm.handle, self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
+                                                        int(iters), None, 0, self.stream))
             return
         import torch.distributed as dist
 
@@ -401,6 +412,13 @@ class DeviceKMeans:
         if self.group is None:
             nat.check(self.L.nnc_kmeans_relocate_windowed(self.x_iter.data_ptr(), ws, ctypes.byref(self.p), n_empty,
                                                           self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(), self.stream))
+            return True
+        if self.comm is not None:
+            need = int(self.L.nnc_kmeans_reloc_scratch_bytes_sharded(self.k, window, self.comm.world))
+            if self._reloc_scratch.numel() < need:
+                self._reloc_scratch = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            nat.check(self.L.nnc_kmeans_relocate_windowed_sharded(self.comm.handle, self.x_iter.data_ptr(), ws, ctypes.byref(self.p), n_empty,
+                                                                  self._reloc_scratch.data_ptr(), self._reloc_scratch.numel(), self.stream))
             return True
         import torch.distributed as dist
 

@@ -119,8 +119,10 @@ def initial_centroids(x: torch.Tensor, bits: int, mode: str, cdfs=None, group=No
 
 def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int = 4, mode: str = "linear",
                    with_cdf: bool | None = None, group=None, huffman: bool = True,
-                   want_values: bool = True) -> LayerResult:
-    """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part."""
+                   want_values: bool = True, comm=None) -> LayerResult:
+    """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part.
+    ``group``: torch.distributed group of one rank per GPU when `x` is a shard; ``comm`` (sharding.RcclComm over the same
+    ranks) moves the per-iteration exchange of the fit into the C library."""
     x = x.reshape(-1)
     ops._require_cuda(x, "x", torch.float32)
     n_total = n_min = x.numel()
@@ -154,7 +156,7 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         space = np.linspace(np.float32(lstats.min), np.float32(lstats.max), num=2 ** bits).astype(np.float32)
     else:
         space = initial_centroids(x, bits, mode, cdfs, group, n_total)
-    km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min)
+    km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min, comm=comm)
     model, values = km.fit(want_values=want_values)
     counts = lengths = lhist = total = None
     counts_d = None

@@ -75,3 +75,53 @@ def allreduce_sum_(t: torch.Tensor, group) -> torch.Tensor:
 def total_count(n_local: int, device, group) -> int:
     t = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
     return int(allreduce_sum_(t, group).item())
+
+
+class RcclComm:
+    """The library's own RCCL communicator (include/nnc.h, nnc_comm_*): with it the per-iteration exchange of a sharded
+    fit -- streaming pass, all-reduce of the 2K int64 sums / counts, finalize -- is enqueued by ONE call into the C
+    library per batch of iterations (nnc_kmeans_iterate_sharded), like the single-GPU loop, instead of three
+    Python-issued calls per iteration.  Built from a torch.distributed group of one rank per GPU, which only
+    carries the 128-byte id to the other ranks."""
+
+    def __init__(self, group, device: torch.device):
+        import ctypes
+
+        import torch.distributed as dist
+
+        from . import _native as nat
+
+        self.L = nat.load()
+        self.group = group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        torch.cuda.set_device(device)
+        buf = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            nat.check(self.L.nnc_comm_unique_id(buf, 128))
+        backend = dist.get_backend(group)
+        idt = torch.tensor(list(buf), dtype=torch.uint8, device=device if backend == "nccl" else "cpu")
+        dist.broadcast(idt, src=dist.get_global_rank(group, 0), group=group)
+        raw = bytes(idt.cpu().tolist())
+        idbuf = ctypes.create_string_buffer(raw, 128)
+        handle = ctypes.c_void_p()
+        nat.check(self.L.nnc_comm_init(ctypes.byref(handle), idbuf, 128, self.rank, self.world))
+        self.handle = handle
+
+    def allreduce_(self, t: torch.Tensor, op: str = "sum") -> torch.Tensor:
+        from . import _native as nat
+
+        dt = {torch.int64: 0, torch.int32: 1, torch.float32: 2}[t.dtype]
+        nat.check(self.L.nnc_comm_allreduce(self.handle, t.data_ptr(), t.numel(), dt, {"sum": 0, "max": 1, "min": 2}[op],
+                                            torch.cuda.current_stream(t.device).cuda_stream))
+        return t
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.nnc_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover - interpreter teardown order
+        try:
+            self.close()
+        except Exception:
+            pass

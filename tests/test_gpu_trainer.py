@@ -150,9 +150,56 @@ def test_sharded_code_path_with_one_rank_group(trainer_mod):
             assert np.array_equal(a.model.labels_, b.model.labels_)
             assert torch.equal(a.values, b.values)
             assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
+        # the same with the exchange inside the C library: the library's own RCCL communicator (nnc_comm_*),
+        # nnc_kmeans_iterate_sharded and nnc_kmeans_relocate_windowed_sharded (key merge on the device)
+        from neural_network_compression_amd import sharding
+
+        comm = sharding.RcclComm(group, torch.device("cuda:0"))
+        try:
+            assert comm.world == 1 and comm.rank == 0
+            t = torch.tensor([5, -7, 11], dtype=torch.int64, device="cuda")
+            assert comm.allreduce_(t.clone(), "sum").tolist() == [5, -7, 11] and comm.allreduce_(t.clone(), "max").tolist() == [5, -7, 11]
+            for bits, mode, q in [(4, "density", 1), (5, "forgy", 1), (8, "density", None)]:
+                np.random.seed(11)
+                a = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=q, bits=bits, mode=mode)
+                np.random.seed(11)
+                b = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=q, bits=bits, mode=mode, group=group, comm=comm)
+                assert a.model.n_iter_ == b.model.n_iter_ and a.model.n_relocations_ == b.model.n_relocations_
+                assert a.model.n_reloc_windowed_ == b.model.n_reloc_windowed_ and a.model.reloc_tie_ == b.model.reloc_tie_
+                assert np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_)
+                assert np.array_equal(a.model.labels_, b.model.labels_)
+                assert torch.equal(a.values, b.values)
+                assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
+        finally:
+            comm.close()
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_merge_of_the_ranks_farthest_keys(trainer_mod):
+    """The key merge of the sharded windowed relocation (nnc_merge_keys: every rank's descending list of farthest-sample
+    keys -> the overall top, descending, padding dropped) against a plain sort, for 1..8 lists with ties between lists."""
+    from neural_network_compression_amd import _native as nat
+
+    L = nat.load()
+    rng = np.random.RandomState(9)
+    for nlists in (1, 2, 3, 8):
+        for per in (2, 17, 258, 1033):
+            lists = []
+            for _ in range(nlists):
+                nreal = rng.randint(0, per + 1)
+                keys = rng.randint(1, 50 if per < 100 else 1 << 40, size=nreal).astype(np.int64)   # small range: ties between lists
+                keys = np.sort(keys)[::-1]
+                pad = np.full(per - nreal, rng.choice([0, -1]), dtype=np.int64)
+                lists.append(np.concatenate([keys, pad]))
+            flat = np.concatenate(lists)
+            want = np.sort(flat[flat > 0])[::-1][:per]
+            want = np.concatenate([want, np.zeros(per - want.size, dtype=np.int64)])
+            out = torch.empty(per, dtype=torch.int64, device="cuda")
+            nat.check(L.nnc_merge_keys(torch.from_numpy(flat).cuda().data_ptr(), nlists, per, out.data_ptr(), per,
+                                       torch.cuda.current_stream().cuda_stream))
+            assert np.array_equal(out.cpu().numpy(), want), (nlists, per)
 
 
 def test_lenet5_trainer_prune_and_quantize_match_oracle(trainer_mod):
