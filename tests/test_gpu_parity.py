@@ -491,8 +491,8 @@ def test_farthest_selection_rule(nnc):
     xd = dev(nnc, x)
     for name, d in cases.items():
         for m in (1, 7, 150):
-            keys = km._top_keys(dev(nnc, d), xd, m).cpu().numpy()
-            order = np.lexsort((x, d))[::-1][:m]
+            keys = km._top_keys(dev(nnc, d), xd, m).cpu().numpy()   # the m farthest and the runner-up
+            order = np.lexsort((x, d))[::-1][:m + 1]
             got_d = (keys >> 32).astype(np.uint32).view(np.float32)
             lo = (keys & 0xFFFFFFFF).astype(np.uint32)
             got_x = np.where(lo & 0x80000000, lo & 0x7FFFFFFF, ~lo).astype(np.uint32).view(np.float32)
