@@ -170,6 +170,9 @@ typedef struct nnc_kmeans_params {
     float x_mean;      /* NumPy float32 mean of the whole vector */
     float tol;         /* float32(np.var(x)) * float32(1e-4) */
     float lo, hi;      /* min and max of the centred data x - x_mean (float32) */
+    const int64_t *prefix_dev; /* NULL: the vector handed to the iterations is in any order (streaming pass over all of it).
+                          Else it is sorted ascending (nnc_sort_f32) and prefix_dev the block prefix sums built from it by
+                          nnc_kmeans_prefix_build: an iteration then only looks up the K - 1 cluster boundaries (below) */
 } nnc_kmeans_params;
 
 typedef struct nnc_kmeans_status {
@@ -191,6 +194,18 @@ typedef struct nnc_kmeans_status {
 
 int32_t nnc_fix_shift(float absmax, int64_t n_total);
 size_t nnc_kmeans_workspace_bytes(int32_t k);
+
+/* Rank-boundary form of the iteration on a value-sorted vector.  In one dimension a cluster is a stretch of the sorted
+ * vector; scikit-learn's float32 arg-min (_k_means_lloyd.pyx:196-213) can deviate from "nearest centre" only inside a
+ * narrow zone around each midpoint (the bound of include/nnc.h's E-step note).  So per iteration every boundary is located by
+ * a 64-ary search (one wave per boundary), the sums of the stretches that are certain come from block prefix sums of the
+ * fixed-point images (differences of exact integers: the same sums as adding the members one by one), and only the samples
+ * inside a zone are evaluated with the exact float32 expression.  Same labels, same sums, O(K log N) instead of O(N) reads.
+ * prefix_dev: nnc_kmeans_prefix_bytes(n) bytes; build once per fit, after nnc_kmeans_init's x_mean / fix_shift are known.
+ * x_sorted must be 16-byte aligned. */
+#define NNC_PREFIX_BLOCK 256
+size_t nnc_kmeans_prefix_bytes(int64_t n);
+int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_params *p, int64_t *prefix_dev, void *stream);
 
 /* centers_init_dev: k float32, un-centred (the reference's `space`).  Resets the state. */
 int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -317,6 +332,39 @@ int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code,
 
 /* counts_dev[j] += #{ i : labels[i] == j }  (caller zeroes counts_dev; int64[k]). */
 int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * k-means++ seeding: the reference's 4th initialisation mode, get_quantized_weight(mode="kmeans++") =
+ * KMeans(n_clusters=2**bits).fit(...) (common/utility.py:228-232) -> scikit-learn's _kmeans_plusplus
+ * (cluster/_kmeans.py:163-253) on the mean-centred float32 weights.  The host draws the random numbers from NumPy's
+ * global generator in scikit-learn's order (one for the first seed, nnc_kmeanspp_trials(k) uniforms per further seed)
+ * and resolves the first seed's index; the device runs the k - 1 rounds of D^2 sampling without a host round trip:
+ * distances in scikit-learn's upcast form ((-2 * (c * x)) + c * c) + x * x in float64 -> float32, clipped at 0;
+ * potentials and running sums in float64 in a fixed order (csrc/nnc_pp.hip; scikit-learn's own potential is a float32
+ * BLAS dot whose order is the BLAS kernel's, so its last bits -- and with them, on long vectors, a candidate now and
+ * then -- are not reproducible by anybody).  Single GPU (the whole vector).
+ *   uniforms_dev : (k - 1) * nnc_kmeanspp_trials(k) float64 in [0, 1), round-major
+ *   seeds_out_dev[k] : the seeds, centred (x[id] - x_mean in float32), in the order chosen; seed_ids_out_dev[k]: their indices
+ *   ws: nnc_kmeanspp_workspace_bytes(n, k) bytes, 256-byte aligned.
+ * ---------------------------------------------------------------------------------- */
+int32_t nnc_kmeanspp_trials(int32_t k);
+size_t nnc_kmeanspp_workspace_bytes(int64_t n, int32_t k);
+int nnc_kmeanspp_seed_f32(const float *x, int64_t n, float x_mean, int32_t k, int64_t first_id, const double *uniforms_dev,
+                          float *seeds_out_dev, int64_t *seed_ids_out_dev, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Centroid fine-tuning (Deep Compression's trained quantization).  The reference describes it and leaves it out "because the
+ * latency is excessive: for each single batch in every epoch, I should have scanned all the gradients"
+ * (papers/lat/report.tex:149-158):   dL/dC_k = sum over the weights with centroid index k of dL/dW.
+ * nnc_centroid_grad_f32: sums_dev[k] (int64, zeroed here) = sum of rint(grad * 2^fix_shift) per centroid index
+ *   (fix_shift = nnc_fix_shift(max |grad|, n): exact integer sums, independent of order and of GPU count -- a sharded
+ *   caller all-reduces them); counts_dev[k] (may be NULL) = members per index.  dL/dC_k = ldexp(sums[k], -fix_shift).
+ * nnc_gather_f32: out[i] = centers_dev[labels[i]], the decode step cluster_centers_[labels_] (common/utility.py:239), for
+ *   writing updated centroids back into the layer.
+ * ---------------------------------------------------------------------------------- */
+int nnc_centroid_grad_f32(const float *grad, const void *labels, int label_bytes, int64_t n, int32_t k, int32_t fix_shift,
+                          int64_t *sums_dev, int64_t *counts_dev, void *stream);
+int nnc_gather_f32(const float *centers_dev, int32_t k, const void *labels, int label_bytes, int64_t n, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-GPU: the vector is sharded across one process per GPU (contiguous shards starting on multiples of

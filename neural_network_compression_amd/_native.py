@@ -38,6 +38,7 @@ class KMeansParams(ctypes.Structure):
         ("n", c_i64), ("n_total", c_i64), ("k", c_i32), ("max_iter", c_i32), ("fix_shift", c_i32),
         ("grid_log2", c_i32), ("replicas_log2", c_i32), ("flags", c_i32),
         ("x_mean", c_f32), ("tol", c_f32), ("lo", c_f32), ("hi", c_f32),
+        ("prefix_dev", c_void_p),
     ]
 
 
@@ -72,6 +73,8 @@ SIGNATURES = {
     "nnc_sort_pruned_f32": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_fix_shift": (c_i32, [c_f32, c_i64]),
     "nnc_kmeans_workspace_bytes": (c_size, [c_i32]),
+    "nnc_kmeans_prefix_bytes": (c_size, [c_i64]),
+    "nnc_kmeans_prefix_build": (c_int, [c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
     "nnc_kmeans_init": (c_int, [c_void_p, c_size, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
     "nnc_kmeans_set_centers": (c_int, [c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_int, c_void_p]),
     "nnc_kmeans_accumulate": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_void_p]),
@@ -99,6 +102,11 @@ SIGNATURES = {
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
+    "nnc_kmeanspp_trials": (c_i32, [c_i32]),
+    "nnc_kmeanspp_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "nnc_kmeanspp_seed_f32": (c_int, [c_void_p, c_i64, c_f32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_centroid_grad_f32": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "nnc_gather_f32": (c_int, [c_void_p, c_i32, c_void_p, c_int, c_i64, c_void_p, c_void_p]),
     "nnc_comm_unique_id": (c_int, [c_void_p, c_size]),
     "nnc_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_size, c_i32, c_i32]),
     "nnc_comm_destroy": (c_int, [c_void_p]),

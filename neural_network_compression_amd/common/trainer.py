@@ -75,19 +75,63 @@ class Trainer(ABC):
     # ------------------------------------------------------------------ the hot path
     def quantize(self, test_dataset: LeNetDataset, with_cumulative_weight_distribution: bool,
                  maximum_centroid_bits: int, k_means_initialization_mode: str) -> float:
+        self.quantized_models_by_layer = {}   # layer -> [fitted model or None per tensor]: what fine_tune_centroids needs
         for _layer_name, layer in self.neural_network.get_config().items():
             quantized_weights_and_bias = []
+            models = []
             for params in layer.get_weights():
                 cdfs = None
                 if with_cumulative_weight_distribution:
                     # the reference strips exact zeros with numpy.delete first (trainer.py:55-59);
                     # the device kernels skip them instead -- same histogram, no compaction
                     cdfs = utility.get_weight_distribution(params, skip_zeros=True)
-                quantized_weights_and_bias.append(
-                    utility.get_quantized_weight(params, bits=maximum_centroid_bits,
-                                                 mode=k_means_initialization_mode, cdfs=cdfs)[0])
+                quantized, model = utility.get_quantized_weight(params, bits=maximum_centroid_bits,
+                                                                mode=k_means_initialization_mode, cdfs=cdfs)
+                quantized_weights_and_bias.append(quantized)
+                models.append(model)
             layer.set_weights(quantized_weights_and_bias)
+            if models:
+                self.quantized_models_by_layer[layer] = models
         return self._get_accuracy(test_dataset)
+
+    def fine_tune_centroids(self, train_dataset: LeNetDataset, test_dataset: LeNetDataset, epochs: int,
+                            learning_rate: float = 1e-3) -> List[float]:
+        """Deep Compression's trained quantization, which the reference describes and leaves out as too slow on the host
+        (papers/lat/report.tex:149-158): after ``quantize`` the centroid indices stay fixed; per batch the gradient of
+        every quantized tensor is summed per centroid (ops.centroid_gradient: dL/dC_k = sum of dL/dW over cluster k, on
+        the device), the centroids take a plain gradient step and the tensor is re-decoded from its indices
+        (ops.gather).  Tensors that passed through unquantized are left alone.  Returns the accuracy per epoch."""
+        models = getattr(self, "quantized_models_by_layer", None)
+        if not models:
+            raise RuntimeError("fine_tune_centroids needs a quantized network: call quantize first")
+        x = self._to_device(train_dataset.input_data).float()
+        y = self._to_device(train_dataset.output_data).float()
+        centers = {}
+        for layer, ms in models.items():
+            for ti, m in enumerate(ms):
+                if m is not None:
+                    centers[(layer, ti)] = torch.from_numpy(np.ascontiguousarray(m.cluster_centers_.ravel())).to(self.device)
+        accuracies = []
+        for _ in range(epochs):
+            for xb, yb in _batches(x, y):
+                self.optimizer.zero_grad(set_to_none=True)
+                self._get_error(xb, yb).backward()
+                with torch.no_grad():
+                    for layer, ms in models.items():
+                        tensors = layer.get_weights()
+                        params = layer.trainable_tensors() if hasattr(layer, "trainable_tensors") else list(layer.parameters())
+                        for ti, m in enumerate(ms):
+                            if m is None or params[ti].grad is None:
+                                continue
+                            c = centers[(layer, ti)]
+                            g = ops.centroid_gradient(params[ti].grad.contiguous(), m.labels_compact_, c.numel())
+                            c.sub_((learning_rate * g).to(torch.float32))
+                            tensors[ti] = ops.gather(c, m.labels_compact_).view(tensors[ti].shape)
+                        layer.set_weights(tensors)
+            accuracies.append(self._get_accuracy(test_dataset))
+        for (layer, ti), c in centers.items():
+            models[layer][ti].cluster_centers_ = c.cpu().numpy().reshape(-1, 1)
+        return accuracies
 
     def _prune_parameters(self, with_standard_deviation_smoothing: bool) -> None:
         for layer, (weight_threshold, bias_threshold) in self._layers_to_prune_with_threshold.items():

@@ -151,6 +151,52 @@ def _init_space(x: torch.Tensor, n: int, bits: int, mode: str, cdfs):
     raise Exception(" error mode not found")
 
 
+def _first_seed_index(u: float, n: int) -> int:
+    """random_state.choice(n, p=w / w.sum()) for n unit weights, given its one uniform draw u (numpy mtrand.choice: the
+    float64 cdf of the probabilities, normalised by its last entry, searched with side="right").  The probabilities are
+    n copies of p0 = float32(1) / float32(n); their partial sums j * p0 are exact in float64 below 2^29 samples, so
+    cdf[j - 1] = fl64(j * p0 / (n * p0)) and the index is the number of entries <= u."""
+    p0 = np.float64(np.float32(1.0) / np.float32(n))
+    tot = np.float64(n) * p0
+    j = max(0, min(n, int(u * n)))
+    while j < n and (np.float64(j + 1) * p0) / tot <= u:
+        j += 1
+    while j > 0 and (np.float64(j) * p0) / tot > u:
+        j -= 1
+    return min(j, n - 1)
+
+
+def kmeans_plusplus_init(x: torch.Tensor, k: int, stats=None):
+    """scikit-learn's k-means++ seeds for the flattened float32 CUDA vector x, drawn from NumPy's GLOBAL generator
+    exactly as ``KMeans(n_clusters=k).fit`` would draw them (cluster/_kmeans.py:163-253, reached from the reference's
+    utility.py:229-230).  Returns (seeds float32[k] = x[indices], indices int64[k]); see include/nnc.h
+    (nnc_kmeanspp_seed_f32) for what is and is not reproducible of scikit-learn's float32 BLAS potential."""
+    import ctypes
+
+    from .. import _native as nat
+
+    L = nat.load()
+    n = x.numel()
+    if n < k:
+        raise ValueError(f"n_samples={n} should be >= n_clusters={k}.")
+    if n >= 1 << 29:
+        raise ValueError("kmeans++ seeding supports fewer than 2^29 samples")
+    if stats is None:
+        stats = _kmeans.LayerStats(x)
+    trials = int(L.nnc_kmeanspp_trials(k))
+    u0 = np.random.random_sample()
+    first = _first_seed_index(u0, n)
+    uni = np.random.uniform(size=(k - 1) * trials) if k > 1 else np.zeros(0)   # uniform(size=trials) per round, in order
+    uni_d = torch.from_numpy(np.ascontiguousarray(uni, dtype=np.float64)).to(x.device) if k > 1 else None
+    seeds = torch.empty(k, dtype=torch.float32, device=x.device)
+    ids = torch.empty(k, dtype=torch.int64, device=x.device)
+    ws_bytes = int(L.nnc_kmeanspp_workspace_bytes(n, k))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    nat.check(L.nnc_kmeanspp_seed_f32(x.data_ptr(), n, float(stats.mean), k, first, ops._ptr(uni_d), seeds.data_ptr(), ids.data_ptr(),
+                                      ws.data_ptr(), ws_bytes, ops._stream(x)))
+    return x[ids].cpu().numpy(), ids.cpu().numpy()
+
+
 def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=None):
     """Replace every weight by the centroid of its k-means cluster (2**bits centroids;
     2**bits + 1 for ``density``).  Returns ``(quantized weights, fitted model)`` where the
@@ -159,8 +205,8 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=N
 
     Same corner cases: fewer than ``2**bits + 1`` weights -> prints "not enough bits" and
     returns ``(layer_weight, None)``; unknown mode, or ``density`` without ``cdfs`` ->
-    ``Exception(" error mode not found")``.  ``kmeans++`` (a 4th mode of the reference that
-    the hot path does not cover) raises NotImplementedError.
+    ``Exception(" error mode not found")``.  ``kmeans++`` (utility.py:228-232) seeds with scikit-learn's
+    k-means++ from NumPy's global generator (kmeans_plusplus_init), then runs the same Lloyd fit.
 
     ``group``: a torch.distributed process group when ``layer_weight`` is this rank's
     contiguous shard of a longer vector (shards start on multiples of 8192 elements)."""
@@ -168,11 +214,19 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=N
     if group is None and n < (2 ** bits) + 1:
         print("not enough bits:", n, " vs ", 2 ** bits)
         return layer_weight, None
-    if mode == "kmeans++":
-        raise NotImplementedError("kmeans++ initialisation is outside the accelerated path")
-    if mode not in ("linear", "forgy") and not (mode == "density" and cdfs is not None):
+    if mode not in ("linear", "forgy", "kmeans++") and not (mode == "density" and cdfs is not None):
         raise Exception(" error mode not found")
     x, was_numpy = _to_device(layer_weight)
+    if mode == "kmeans++":
+        # utility.py:228-232: KMeans(n_clusters=2 ** bits) with scikit-learn's defaults (k-means++ seeding from the global
+        # NumPy generator, one run, max_iter 300, tol 1e-4)
+        if group is not None:
+            raise NotImplementedError("kmeans++ seeding needs the whole vector on one GPU")
+        space, _ = kmeans_plusplus_init(x, 2 ** bits)
+        km = _kmeans.DeviceKMeans(x, space)
+        model, values = km.fit(want_values=True)
+        shape = tuple(layer_weight.shape)
+        return (values.cpu().numpy().reshape(shape), model) if was_numpy else (values.view(shape), model)
     if group is not None and mode != "density":
         raise NotImplementedError("sharded fits take an explicit init: use kmeans.DeviceKMeans")
     space = _init_space(x, n, bits, mode, cdfs)

@@ -739,6 +739,11 @@ struct KmWs {
     long long prev_counts[NNC_KMAX];        // label counts of the previous iteration (before any relocation edit)
     long long shard_sum[KM_NSHARD][NNC_KMAX]; // sorted index order of tab[cur]
     unsigned long long shard_cnt[KM_NSHARD][NNC_KMAX];
+    // k_bounds: long stretches of samples whose cluster float32 cannot tell from the zones alone, cut into tiles any wave
+    // may take (two self-validating words per record, see k_bounds); emptied by the kernel that consumes the sums
+    int32_t q_n, q_pad;
+    unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
+    int32_t q_next[NNC_KMAX];
     KmTab tab[2];
 };
 
@@ -1248,6 +1253,328 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 }
 
 
+// ---- the rank-boundary iteration (value-sorted vector + block prefix sums) ---------------------
+//
+// Wave j owns the j-th distinct centre (value order) and the boundary above it.  From the zones k_finalize left
+// (zl / zr: outside [zl[p], zr[p]] centre p cannot be scikit-learn's float32 arg-min) it derives
+//     L_j = min over q > j of zl[q]      below L_j no centre above j can win
+//     U_j = max over q <= j of zr[q]     above U_j no centre up to j can win
+// and locates three ranks in the sorted vector by 64-ary search (64 probes per round, all three searches in flight together):
+//     a_j = #{x~ < L_j},  b_j = #{x~ <= U_j},  b_{j-1}.
+// Samples [b_{j-1}, a_j) are certainly centre j's: their count is a difference of ranks, their fixed-point sum a difference
+// of prefix sums (block prefix + at most 255 images added by the wave).  Samples [max(a_j, b_{j-1}), b_j) cannot be decided
+// from the zones; every one of them is evaluated with the exact float32 expression over the centres that can still win
+// (j .. max{r : zl[r] <= U_j}; almost always j and j + 1), ties to the lowest original index.  The stretches of all waves
+// partition the vector.  A long undecided stretch (two centres closer than float32 can tell apart make their whole
+// neighbourhood undecided) is published as tiles that any wave of the launch may take.
+#ifdef NNC_DIAG
+#define KBSTAMP(slot, val) do { if (NNC_KM_TRACE_PTR && lane == 0) { NNC_KM_TRACE_PTR[(slot)] = (unsigned long long)(val); __threadfence_system(); } } while (0)
+#else
+#define KBSTAMP(slot, val) do { } while (0)
+#endif
+#define KM_PB NNC_PREFIX_BLOCK
+#define KM_TILE 2048
+#define KM_Q_VALID (1ull << 62)
+
+// a value every lane holds alike, moved to scalar registers (so that the control flow that depends on it is scalar)
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni_ll(long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xFFFFFFFFll));
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ long long wave_sum_ll(long long v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wave_min_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+
+// sum of fix(x~) over the first r samples: block prefix + the wave adds the rest of r's block
+__device__ __forceinline__ long long km_prefix_at(const float *__restrict__ xs, const long long *__restrict__ pblk, long long r,
+                                                  long long n, float mean, int Sft, int lane)
+{
+    const long long blk = r >> 8, base = blk << 8;
+    const int rem = (int)(r - base);
+    long long acc = 0;
+    if (rem > 0) { // wave-uniform
+        const long long i0 = base + 4 * lane;
+        if (base + KM_PB <= n) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + i0);
+            const int left = rem - 4 * lane; // how many of the four are below r
+            if (left > 0) acc += fix_f32(v.x - mean, Sft);
+            if (left > 1) acc += fix_f32(v.y - mean, Sft);
+            if (left > 2) acc += fix_f32(v.z - mean, Sft);
+            if (left > 3) acc += fix_f32(v.w - mean, Sft);
+        } else {
+            for (int u = 0; u < 4; u++) if (i0 + u < r) acc += fix_f32(xs[i0 + u] - mean, Sft);
+        }
+        acc = wave_sum_ll(acc);
+    }
+    return pblk[blk] + acc;
+}
+
+__device__ __forceinline__ void km_shard_add(KmWs *ws, int p, long long sum, unsigned long long cnt)
+{
+    if (cnt) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&ws->shard_sum[p & (KM_NSHARD - 1)][p]), (unsigned long long)sum);
+        atomicAdd(&ws->shard_cnt[p & (KM_NSHARD - 1)][p], cnt);
+    }
+}
+
+// exact labels of the samples [s, e) whose candidates are the centres plo .. phi (value order), added to the sums
+__device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, long long s, long long e, int plo, int phi, const KmTab *__restrict__ tab,
+                                                KmWs *ws, float mean, int Sft, int lane)
+{
+    s = uni_ll(s); e = uni_ll(e); plo = uni_i(plo); phi = uni_i(phi);
+    if (phi <= plo) { // (cannot happen for an undecided stretch; kept total: everything is plo's)
+        long long sum = 0;
+        unsigned cnt = 0;
+        for (long long i = s + lane; i < e; i += 64) { sum += fix_f32(xs[i] - mean, Sft); cnt++; }
+        sum = wave_sum_ll(sum);
+        const long long c = wave_sum_ll((long long)cnt);
+        if (lane == 0) km_shard_add(ws, plo, sum, (unsigned long long)c);
+        return;
+    }
+    if (phi == plo + 1) {
+        const float2 c0 = tab->cand[plo], c1 = tab->cand[plo + 1];
+        const bool tie1 = tab->orig[plo + 1] < tab->orig[plo];
+        long long s0 = 0, s1 = 0;
+        unsigned n0 = 0, n1 = 0;
+        KBSTAMP(16 * plo + 1, s);
+        for (long long i0 = s; i0 < e; i0 += 256) { // four loads in flight per lane
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const long long i = i0 + lane + 64 * u; v[u] = i < e ? xs[i] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const long long i = i0 + lane + 64 * u;
+                if (i < e) {
+                    const float xc = v[u] - mean;
+                    const float d0 = c0.y + (-2.0f * (xc * c0.x));
+                    const float d1 = c1.y + (-2.0f * (xc * c1.x));
+                    const int q = fix_f32(xc, Sft);
+                    if (d1 < d0 || (d1 == d0 && tie1)) { s1 += q; n1++; } else { s0 += q; n0++; }
+                }
+            }
+        }
+        KBSTAMP(16 * plo + 2, e);
+        s0 = wave_sum_ll(s0); s1 = wave_sum_ll(s1);
+        KBSTAMP(16 * plo + 3, s0);
+        const long long m0 = wave_sum_ll((long long)n0), m1 = wave_sum_ll((long long)n1);
+        KBSTAMP(16 * plo + 4, m1);
+        if (lane == 0) { km_shard_add(ws, plo, s0, (unsigned long long)m0); km_shard_add(ws, plo + 1, s1, (unsigned long long)m1); }
+        KBSTAMP(16 * plo + 5, 0xD0E);
+        return;
+    }
+    // three or more centres within rounding distance of each other: the general scan, one run of equal winners at a time
+    int run_p = -1;
+    unsigned run_n = 0;
+    long long run_s = 0;
+    for (long long i = s + lane; i < e; i += 64) {
+        const float xc = xs[i] - mean;
+        float2 cc = tab->cand[plo];
+        float bestd = cc.y + (-2.0f * (xc * cc.x));
+        int best = plo;
+        for (int c = plo + 1; c <= phi; c++) {
+            cc = tab->cand[c];
+            const float d = cc.y + (-2.0f * (xc * cc.x));
+            if (d < bestd || (d == bestd && tab->orig[c] < tab->orig[best])) { bestd = d; best = c; }
+        }
+        if (best != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best; run_n = 0; run_s = 0; }
+        run_n++;
+        run_s += fix_f32(xc, Sft);
+    }
+    if (run_n) km_shard_add(ws, run_p, run_s, run_n);
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
+                                               const long long *__restrict__ pblk)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (!(which & 2) && (ws->st.done | ws->st.paused)) return; // (which & 2: counting pass after the fit)
+    const KmTab *__restrict__ tab = &ws->tab[ws->cur ^ (which & 1)];
+    const int ku = tab->ku;
+    const float mean = ws->p.x_mean;
+    const int Sft = ws->p.fix_shift;
+    if (j < ku) {
+        // ---- the zone ends that bound this wave's stretches
+        double Uj = -INFINITY, Ujm1 = -INFINITY, Lj = INFINITY;
+        for (int q = lane; q < ku; q += 64) {
+            const double zr = tab->zr[q], zl = tab->zl[q];
+            if (q <= j) Uj = fmax(Uj, zr);
+            if (q < j) Ujm1 = fmax(Ujm1, zr);
+            if (q > j) Lj = fmin(Lj, zl);
+        }
+        Uj = wave_max_d(Uj); Ujm1 = wave_max_d(Ujm1); Lj = wave_min_d(Lj);
+        const bool top = j == ku - 1; // no boundary above the last centre
+        // ---- three searches in lock step.  State k: the answer lies in [lo, hi]; hi is n or a position known to satisfy the test
+        long long lo[3] = {0, 0, 0}, hi[3] = {n, n, n};
+        const double T[3] = {Lj, Uj, Ujm1};
+        if (top) { lo[0] = n; lo[1] = n; }   // a = b = n
+        if (j == 0) hi[2] = 0;               // b_{-1} = 0
+        while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2])) {
+            float v[3];
+            long long step[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                v[k] = 0.0f; step[k] = 1;
+                if (lo[k] < hi[k]) {
+                    const long long len = hi[k] - lo[k];
+                    step[k] = (len + 63) >> 6;
+                    long long off = (long long)(lane + 1) * step[k];
+                    if (off > len) off = len;
+                    v[k] = xs[lo[k] + off - 1];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (lo[k] < hi[k]) {
+                    const long long len = hi[k] - lo[k];
+                    const double xc = (double)(v[k] - mean);
+                    const bool pred = (k == 0) ? (xc >= T[k]) : (xc > T[k]);
+                    const unsigned long long bal = __ballot(pred);
+                    if (bal == 0ull) lo[k] = hi[k];
+                    else {
+                        const int f = __ffsll((long long)bal) - 1;
+                        long long offf = (long long)(f + 1) * step[k];
+                        if (offf > len) offf = len;
+                        long long offp = (long long)f * step[k];
+                        if (offp > len) offp = len;
+                        hi[k] = lo[k] + offf - 1;
+                        lo[k] = lo[k] + offp; // one past the last probe that failed (lo itself if the first probe passed)
+                    }
+                }
+            }
+        }
+        const long long a = uni_ll(lo[0]), b = uni_ll(lo[1]), bm = uni_ll(lo[2]);
+        KBSTAMP(16 * j + 8, a); KBSTAMP(16 * j + 9, b); KBSTAMP(16 * j + 10, bm);
+        // ---- this centre's certain stretch [bm, a)
+        if (a > bm) {
+            const long long sum = km_prefix_at(xs, pblk, a, n, mean, Sft, lane) - km_prefix_at(xs, pblk, bm, n, mean, Sft, lane);
+            if (lane == 0) km_shard_add(ws, j, sum, (unsigned long long)(a - bm));
+        }
+        // ---- the undecided stretch above it, [max(a, bm), b)
+        const long long s = a > bm ? a : bm;
+        if (b > s) {
+            int phi = j;
+            for (int q = lane; q < ku; q += 64) if (q > j && tab->zl[q] <= Uj) phi = q;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) phi = max(phi, __shfl_xor(phi, off));
+            phi = uni_i(phi);
+            if (b - s > KM_TILE) { // long: as tiles, for everybody
+                int r = 0;
+                if (lane == 0) r = atomicAdd(&ws->q_n, 1);
+                r = uni_i(r);
+                if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
+                    if (lane == 0) {
+                        __hip_atomic_store(&ws->q_w0[r], KM_Q_VALID | ((unsigned long long)j << 40) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&ws->q_w1[r], KM_Q_VALID | ((unsigned long long)phi << 40) | (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                } else km_bounds_range(xs, s, b, j, phi, tab, ws, mean, Sft, lane); // queue full (never reset by a consumer?): do it alone
+            } else km_bounds_range(xs, s, b, j, phi, tab, ws, mean, Sft, lane);
+        }
+    }
+    // ---- tiles of long undecided stretches: every wave of the launch helps; the publisher itself comes through here after its
+    // own record is out, so every tile is taken by somebody who is still running
+    int nrec = 0;
+    if (lane == 0) nrec = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    nrec = min(uni_i(nrec), (int)NNC_KMAX);
+    KBSTAMP(16 * j + 7, 2000 + nrec);
+    for (int r = 0; r < nrec; r++) {
+        unsigned long long w0 = 0, w1 = 0;
+        if (lane == 0) {
+            w0 = __hip_atomic_load(&ws->q_w0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(&ws->q_w1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        w0 = (unsigned long long)uni_ll((long long)w0); w1 = (unsigned long long)uni_ll((long long)w1);
+        if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
+        const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
+        const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
+        const long long ntiles = (e - s + KM_TILE - 1) / KM_TILE;
+        for (;;) {
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&ws->q_next[r], 1);
+            t = uni_i(t);
+            KBSTAMP(16 * j + 6, 1000 + t);
+            if (t >= ntiles) break;
+            const long long ts = s + (long long)t * KM_TILE;
+            const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
+            km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
+        }
+    }
+    KBSTAMP(16 * j + 11, 0xE0D);
+}
+
+// block sums of the fixed-point images of a sorted vector, then their exclusive scan (once per fit)
+__global__ __launch_bounds__(256) void k_prefix_blocks(const float *__restrict__ xs, long long n, float mean, int Sft, long long *__restrict__ pblk)
+{
+    const int lane = threadIdx.x & 63;
+    const long long nblk = (n + KM_PB - 1) / KM_PB;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    for (long long b = wave; b < nblk; b += nwaves) {
+        const long long i0 = b * KM_PB + 4 * lane;
+        long long acc = 0;
+        if ((b + 1) * KM_PB <= n) {
+            const float4 v = *reinterpret_cast<const float4 *>(xs + i0);
+            acc = ((long long)fix_f32(v.x - mean, Sft) + fix_f32(v.y - mean, Sft)) + ((long long)fix_f32(v.z - mean, Sft) + fix_f32(v.w - mean, Sft));
+        } else {
+            for (int u = 0; u < 4; u++) if (i0 + u < n) acc += fix_f32(xs[i0 + u] - mean, Sft);
+        }
+        acc = wave_sum_ll(acc);
+        if (lane == 0) pblk[b + 1] = acc; // shifted by one: the scan turns it into "sum of all blocks before b + 1"
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) pblk[0] = 0;
+}
+
+// in-place inclusive scan of pblk[1 .. nblk] (so that pblk[b] = sum of the blocks before b), one workgroup
+__global__ __launch_bounds__(KM_THREADS) void k_prefix_scan(long long *__restrict__ pblk, long long nblk)
+{
+    __shared__ long long wave_tot[KM_THREADS / 64];
+    __shared__ long long carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    // tiles of KM_THREADS * 8 entries; a thread takes 8 consecutive ones
+    for (long long base = 1; base <= nblk; base += (long long)KM_THREADS * 8) {
+        long long v[8];
+        const long long i0 = base + (long long)tid * 8;
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = (i0 + u <= nblk) ? pblk[i0 + u] : 0;
+#pragma unroll
+        for (int u = 1; u < 8; u++) v[u] += v[u - 1];
+        long long s = v[7];
+        for (int off = 1; off < 64; off <<= 1) { const long long t = __shfl_up(s, off); if (lane >= off) s += t; }
+        if (lane == 63) wave_tot[wv] = s;
+        __syncthreads();
+        long long pre = carry_s;
+        for (int w = 0; w < wv; w++) pre += wave_tot[w];
+        long long tot = 0;
+        for (int w = 0; w < KM_THREADS / 64; w++) tot += wave_tot[w];
+        const long long before = pre + (s - v[7]); // everything before this thread's eight
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (i0 + u <= nblk) pblk[i0 + u] = before + v[u];
+        __syncthreads();
+        if (tid == 0) carry_s += tot;
+        __syncthreads();
+    }
+}
+
 // ---- finalize / prepare kernel (one workgroup) -------------------------------------------
 #define FIN_INIT 0          // build the table for the initial centres
 #define FIN_FROM_SHARDS 1   // single GPU: reduce shards -> partials -> finalize
@@ -1285,6 +1612,12 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
 #define FSTAMP(i) do { if (ftr && tid == 0) ftr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     FSTAMP(0);
     if (tid == 0) ws->cells_pending = 0;
+    {   // the tile queue of the pass that produced these sums (k_bounds) is spent
+        const int qn = min(ws->q_n, (int)NNC_KMAX);
+        for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
+        if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
+        if (tid == 0) ws->q_n = 0;
+    }
     // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
     // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
     const int st_done = ws->st.done, st_paused = ws->st.paused, st_iter = ws->st.iter, reloc_fail = ws->reloc_fail;
@@ -1703,8 +2036,13 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
 // cell g -> candidate range [first p with gc[p] >= g, last p with hc[p] <= g] (both monotone in g);
 // one cell per thread.  The first and last cells are open-ended: everything below lo / above hi
 // is clamped into them.
+// force: build the table of tab[cur ^ which] whatever the pending flag says (the rank-boundary iterations do not need the
+// cell table, so they leave it stale; the kernels that look samples up -- labels, relocation candidates -- ask for it).
+__global__ void k_cells_prepare(KmWs *__restrict__ ws, int which) { ws->tab[ws->cur ^ (which & 1)].n_ovf = 0; }
+
 __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc_kmeans_status *host_st,
-                                                      unsigned long long *host_ticket, unsigned long long ticket)
+                                                      unsigned long long *host_ticket, unsigned long long ticket,
+                                                      int force = 0, int which = 0)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX];
     // the last launch of a batch may carry the host's look-in (nnc_kmeans_iterate_publish): the state is final once
@@ -1714,16 +2052,35 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
         __threadfence_system();
         *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
     }
-    if (!ws->cells_pending) return;
+    if (!force && !ws->cells_pending) return;
     const int G = 1 << ws->glog2;
     const int g = blockIdx.x * KM_THREADS + threadIdx.x;
     if ((int)(blockIdx.x * KM_THREADS) >= G) return;
-    KmTab *tab = &ws->tab[ws->cur];
-    const int ku = ws->ku_cur;
+    KmTab *tab = &ws->tab[ws->cur ^ (which & 1)];
+    const int ku = force ? tab->ku : ws->ku_cur;
     for (int p = threadIdx.x; p < ku; p += KM_THREADS) { gcell[p] = tab->gc[p]; hcell[p] = tab->hc[p]; }
     __syncthreads();
     if (g >= G) return;
     tab->cell[g] = km_cell_entry(g, G, ku, gcell, hcell, &tab->n_ovf, tab->ovf);
+}
+
+static bool km_fused(const nnc_kmeans_params *p)
+{
+    int glog2, rlog2;
+    km_defaults(p, &glog2, &rlog2);
+    return p->k <= KM_FUSE_KMAX && glog2 <= KM_FUSE_GLOG2;
+}
+
+// The cell table of tab[cur ^ which], for the kernels that look samples up, when the iterations did not keep it current.
+static int km_ensure_cells(KmWs *w, const nnc_kmeans_params *p, int which, void *stream)
+{
+    if (!p->prefix_dev || km_fused(p)) return NNC_OK; // streaming iterations keep it current; few centres: k_finalize builds it
+    hipLaunchKernelGGL(k_cells_prepare, dim3(1), dim3(1), 0, S(stream), w, which);
+    LAUNCHCHK("k_cells_prepare");
+    hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, (nnc_kmeans_status *)nullptr,
+                       (unsigned long long *)nullptr, 0ull, 1, which);
+    LAUNCHCHK("k_cells");
+    return NNC_OK;
 }
 
 static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume, void *stream, void *host_mapped = nullptr,
@@ -1732,8 +2089,9 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     // p == nullptr: the caller does not know the fit's parameters (nnc_kmeans_finalize): full width, k_cells builds the table
     const int k = p ? p->k : 0;
     bool fused = false;
-    if (p && mode != FIN_PACK_ONLY) { int glog2, rlog2; km_defaults(p, &glog2, &rlog2); fused = p->k <= KM_FUSE_KMAX && glog2 <= KM_FUSE_GLOG2; }
-    const bool cells = mode != FIN_PACK_ONLY && !fused;
+    if (p && mode != FIN_PACK_ONLY) fused = km_fused(p);
+    const bool lazy = p && p->prefix_dev; // rank-boundary iterations: nobody reads the cell table between two of them
+    const bool cells = mode != FIN_PACK_ONLY && !fused && !lazy;
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
     nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
@@ -1746,7 +2104,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
 #undef KM_LAUNCH_FIN
     LAUNCHCHK("k_finalize");
     if (cells) {
-        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, hs, ht, (unsigned long long)ticket);
+        hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, hs, ht, (unsigned long long)ticket, 0, 0);
         LAUNCHCHK("k_cells");
     }
     return NNC_OK;
@@ -1779,7 +2137,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
         (&ws->shard_sum[0][0])[i] = 0; (&ws->shard_cnt[0][0])[i] = 0;
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
-    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) ws->prev_counts[i] = -1;
+    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; }
+    if (tid == 0) { ws->q_n = 0; ws->q_pad = 0; }
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -1925,8 +2284,39 @@ extern "C" int nnc_debug_set_ablation(int a) { g_ablation = a; return NNC_OK; }
 static const int g_ablation = 0, g_deal = 1;
 #endif
 
+extern "C" size_t nnc_kmeans_prefix_bytes(int64_t n)
+{
+    if (n < 0) return 0;
+    return (size_t)((n + KM_PB - 1) / KM_PB + 2) * sizeof(long long);
+}
+
+extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_params *p, int64_t *prefix_dev, void *stream)
+{
+    if (!p || !prefix_dev || p->n < 0 || (p->n > 0 && !x_sorted)) return fail(NNC_EINVAL, "nnc_kmeans_prefix_build: bad argument");
+    if ((reinterpret_cast<uintptr_t>(x_sorted) & 15) != 0 || (reinterpret_cast<uintptr_t>(prefix_dev) & 7) != 0)
+        return fail(NNC_EINVAL, "nnc_kmeans_prefix_build: x_sorted must be 16-byte aligned, prefix_dev 8-byte aligned");
+    if (p->n >= ((int64_t)1 << 40)) return fail(NNC_EINVAL, "nnc_kmeans_prefix_build: n >= 2^40");
+    const long long nblk = (p->n + KM_PB - 1) / KM_PB;
+    long long *pb = reinterpret_cast<long long *>(prefix_dev);
+    const int grid = (int)std::max<long long>(1, std::min<long long>((nblk + 3) / 4, (long long)cu_count() * 8));
+    hipLaunchKernelGGL(k_prefix_blocks, dim3(grid), dim3(256), 0, S(stream), x_sorted, (long long)p->n, p->x_mean, p->fix_shift, pb);
+    LAUNCHCHK("k_prefix_blocks");
+    hipLaunchKernelGGL(k_prefix_scan, dim3(1), dim3(KM_THREADS), 0, S(stream), pb, nblk);
+    LAUNCHCHK("k_prefix_scan");
+    return NNC_OK;
+}
+
+// one pass of per-cluster sums / counts over this rank's vector: by rank boundaries if the caller attached block prefix sums of a
+// sorted vector (p->prefix_dev), else the streaming kernel
 static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream, int which = 0)
 {
+    if (p->prefix_dev && p->n > 0) {
+        if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
+        const int grid = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
+        hipLaunchKernelGGL(k_bounds, dim3(grid), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev));
+        LAUNCHCHK("k_bounds");
+        return NNC_OK;
+    }
     int glog2, rlog2;
     km_defaults(p, &glog2, &rlog2);
     size_t lds = km_lds_bytes(p->k, glog2, rlog2, true);
@@ -2027,6 +2417,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_counts_from_shards(KmWs *__restr
 {
     const KmTab *tab = &ws->tab[ws->cur ^ (which & 1)];
     const int k = ws->p.k, ku = tab->ku;
+    {   // the tile queue of the counting pass (k_bounds) is spent
+        const int qn = min(ws->q_n, (int)NNC_KMAX);
+        for (int r = threadIdx.x; r < qn; r += KM_THREADS) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
+        __syncthreads();
+        if (threadIdx.x == 0) ws->q_n = 0;
+    }
     for (int j = threadIdx.x; j < k; j += KM_THREADS) counts[j] = 0; // duplicates of a centre own nothing
     __syncthreads();
     for (int p = threadIdx.x; p < ku; p += KM_THREADS) {
@@ -2148,6 +2544,7 @@ static int km_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int 
                      (reinterpret_cast<uintptr_t>(labels_out) & (size_t)(4 * label_bytes - 1)) == 0;
     int grid = km_grid(p.n, lds);
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if ((rc = km_ensure_cells(w, &p, which, stream))) return rc;
     unsigned long long *dh = reinterpret_cast<unsigned long long *>(dist_hist4096_dev);
     if (dh) HIPCHK(hipMemsetAsync(dh, 0, 4096 * sizeof(int64_t), S(stream)));
     if (label_bytes == 2) {
@@ -2839,6 +3236,10 @@ static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmea
     if (!g_reloc_dist_attr[current_device()].load(std::memory_order_acquire)) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)); // + 16 KB static
         g_reloc_dist_attr[current_device()].store(1, std::memory_order_release);
+    }
+    {
+        int rc = km_ensure_cells(reinterpret_cast<KmWs *>(ws), p, 0, stream); // k_reloc_dist looks the candidates up in the cell table
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
                        reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,

@@ -164,7 +164,7 @@ class DeviceKMeans:
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
                  batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
                  reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
-                 n_total: int | None = None, n_min: int | None = None, comm=None):
+                 n_total: int | None = None, n_min: int | None = None, comm=None, rank_boundaries: bool = True):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -256,6 +256,13 @@ class DeviceKMeans:
             self.sorted_everywhere = True   # the caller sorts on every rank or on none
         else:
             self.x_iter = sorted_copy(x, stats) if self.sorted else x
+        # On a sorted vector an iteration only looks up the cluster boundaries (include/nnc.h, nnc_kmeans_prefix_build):
+        # block prefix sums of the fixed-point images, built once
+        self.prefix = None
+        if self.sorted and n > 0 and rank_boundaries and (self.x_iter.data_ptr() & 15) == 0:
+            self.prefix = torch.empty(int(self.L.nnc_kmeans_prefix_bytes(n)), dtype=torch.uint8, device=self.dev)
+            nat.check(self.L.nnc_kmeans_prefix_build(self.x_iter.data_ptr(), ctypes.byref(self.p), self.prefix.data_ptr(), self.stream))
+            self.p.prefix_dev = self.prefix.data_ptr()
 
     # -------------------------------------------------------------- low-level steps
     def publish(self) -> int:

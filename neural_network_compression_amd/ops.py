@@ -185,6 +185,56 @@ def bincount(labels: torch.Tensor, k: int) -> torch.Tensor:
     return counts
 
 
+def _label_bytes(labels: torch.Tensor) -> int:
+    if labels.dtype == torch.uint8:
+        return 1
+    if labels.dtype in (torch.int16, torch.uint16):
+        return 2
+    raise TypeError("labels must be uint8 or 16-bit (QuantizedModel.labels_compact_)")
+
+
+def centroid_gradient(grad: torch.Tensor, labels: torch.Tensor, k: int, group=None) -> torch.Tensor:
+    """dL/dC_j = sum of dL/dW over the weights whose centroid index is j (Deep Compression's centroid fine-tuning,
+    described but left out by the reference, papers/lat/report.tex:149-158) -> float64[k] on the device.
+    Exact fixed-point sums (include/nnc.h, nnc_centroid_grad_f32): independent of order and, with ``group`` (every rank
+    holds a shard of the layer), of the number of GPUs.  One host read (max |grad|) sizes the fixed point."""
+    _require_cuda(grad, "grad", torch.float32)
+    _require_cuda(labels, "labels")
+    g = grad.reshape(-1)
+    if labels.numel() != g.numel():
+        raise ValueError("labels and grad must have the same number of elements")
+    L = nat.load()
+    n = g.numel()
+    if n == 0:
+        return torch.zeros(int(k), dtype=torch.float64, device=g.device)
+    mm, _ = minmax(g)
+    n_total = n
+    if group is not None:
+        from . import sharding
+
+        mm = sharding.allreduce_minmax(mm, group)
+        n_total = sharding.total_count(n, g.device, group)
+    host = mm.cpu().numpy()
+    S = fix_shift(float(max(abs(host[0]), abs(host[1]))), n_total)
+    sums = torch.empty(int(k), dtype=torch.int64, device=g.device)
+    nat.check(L.nnc_centroid_grad_f32(_ptr(g), _ptr(labels), _label_bytes(labels), n, int(k), S, _ptr(sums), 0, _stream(g)))
+    if group is not None:
+        from . import sharding
+
+        sharding.allreduce_sum_(sums, group)
+    return torch.ldexp(sums.to(torch.float64), torch.tensor(-S, device=g.device))
+
+
+def gather(centers: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """cluster_centers_[labels_] on the device (utility.py:239): float32 vector of labels.numel() values."""
+    _require_cuda(centers, "centers", torch.float32)
+    _require_cuda(labels, "labels")
+    L = nat.load()
+    out = torch.empty(labels.numel(), dtype=torch.float32, device=labels.device)
+    nat.check(L.nnc_gather_f32(_ptr(centers), centers.numel(), _ptr(labels), _label_bytes(labels), labels.numel(), _ptr(out), _stream(labels)))
+    return out
+
+
 def huffman_lengths(counts) -> tuple:
     """Host: (lengths uint8[k], hist int64[max_len+1], total_bits) from an index histogram."""
     L = nat.load()

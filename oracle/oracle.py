@@ -459,3 +459,134 @@ def huffman_lengths(counts):
     hist = np.bincount(lengths, minlength=1).astype(np.int64)
     total = int(sum(int(lengths[s]) * counts[s] for s in range(K)))
     return lengths, hist, total
+
+
+# --------------------------------------------------------------------------- kmeans++ mode (utility.py:228-232)
+def _pp_dist(c, xc):
+    """sklearn's _euclidean_distances(c[None, :], X, squared=True) for float32 inputs with one feature
+    (metrics/pairwise.py: float32 data are upcast chunk-wise): ((-2 * (c * x)) + c * c) + x * x in float64, cast to
+    float32, clipped at 0."""
+    c64 = np.float64(c)
+    x64 = xc.astype(np.float64)
+    d = -2.0 * (c64 * x64)
+    d += c64 * c64
+    d += x64 * x64
+    d32 = d.astype(np.float32)
+    np.maximum(d32, 0, out=d32)
+    return d32
+
+
+PP_BLOCK, PP_GROUP = 1024, 256
+
+
+def _pp_block_sums(d32: np.ndarray) -> np.ndarray:
+    """float64 block sums of float32 values in the order csrc/nnc_pp.hip fixes: blocks of 1024 samples; lane l adds the
+    elements {256 t + 4 l + u : t, u = 0..3} of its block in that order; the 64 lane sums meet in an xor butterfly."""
+    n = d32.size
+    nblk = (n + PP_BLOCK - 1) // PP_BLOCK
+    pad = np.zeros(nblk * PP_BLOCK, dtype=np.float64)   # (+0.0 for the missing tail: adding it changes nothing)
+    pad[:n] = d32
+    v = pad.reshape(nblk, 4, 64, 4).transpose(0, 2, 1, 3).reshape(nblk, 64, 16)
+    acc = np.zeros((nblk, 64), dtype=np.float64)
+    for s in range(16):
+        acc = acc + v[:, :, s]
+    lanes = np.arange(64)
+    for off in (32, 16, 8, 4, 2, 1):
+        acc = acc + acc[:, lanes ^ off]
+    return acc[:, 0].copy()
+
+
+def _pp_scan(S: np.ndarray):
+    """W[b] = left-to-right sum of the blocks of b's group before b; G[g] = left-to-right sum of the group totals before g
+    (G[-1] = grand total)."""
+    nblk = S.size
+    ngroups = (nblk + PP_GROUP - 1) // PP_GROUP
+    W = np.zeros(nblk, dtype=np.float64)
+    G = np.zeros(ngroups + 1, dtype=np.float64)
+    for g in range(ngroups):
+        acc = np.float64(0.0)
+        for b in range(g * PP_GROUP, min(nblk, (g + 1) * PP_GROUP)):
+            W[b] = acc
+            acc = acc + S[b]
+        G[g + 1] = G[g] + acc
+    return W, G
+
+
+def _pp_search(closest32, S, W, G, r):
+    """searchsorted(running sum, r) in the three-level order of csrc/nnc_pp.hip (k_pp_select)."""
+    n, nblk = closest32.size, S.size
+    ngroups = G.size - 1
+    hit = np.nonzero(G[1:] >= r)[0]
+    g = int(hit[0]) if hit.size else ngroups - 1
+    b0, b1 = g * PP_GROUP, min(nblk, (g + 1) * PP_GROUP)
+    hit = np.nonzero(G[g] + (W[b0:b1] + S[b0:b1]) >= r)[0]
+    b = b0 + (int(hit[0]) if hit.size else b1 - b0 - 1)
+    base = G[g] + W[b]
+    i0, i1 = b * PP_BLOCK, min(n, (b + 1) * PP_BLOCK)
+    run = np.cumsum(closest32[i0:i1], dtype=np.float64)      # sequential float64 running sum
+    hit = np.nonzero(base + run >= r)[0]
+    return i0 + (int(hit[0]) if hit.size else i1 - i0 - 1)
+
+
+def kmeans_plusplus(xc: np.ndarray, K: int, random_state=None) -> tuple:
+    """sklearn.cluster._kmeans._kmeans_plusplus (cluster/_kmeans.py:163-253 in 1.7.2) on centred float32 data with one
+    feature and unit weights, drawing from the same generator in the same order.  Two orders of summation are pinned
+    down here that scikit-learn leaves open or sequential: the potentials (``closest_dist_sq @ sample_weight``, a float32
+    BLAS GEMV whose order is the BLAS kernel's) and the running sum the candidates are looked up in (np.cumsum in
+    float64) are float64 sums in the blocked order of csrc/nnc_pp.hip.  The potential differs from scikit-learn's in
+    its last bits, so on long vectors a drawn candidate can come out as a neighbouring sample.
+    Returns (centres float32[K], indices)."""
+    rs = np.random.mtrand._rand if random_state is None else random_state
+    xc = _f32c(xc).ravel()
+    n = xc.size
+    n_local_trials = 2 + int(np.log(K))
+    centers = np.empty(K, dtype=np.float32)
+    indices = np.full(K, -1, dtype=np.int64)
+    # random_state.choice(n, p=w / w.sum()): one uniform double, inverted through the float64 cdf of n equal float32
+    # probabilities p0 = float32(1) / float32(n); its partial sums j * p0 are exact below 2^29 samples, so
+    # cdf[j - 1] = fl64(j * p0 / (n * p0)) and the index is #{j : cdf[j - 1] <= u}  (numpy: searchsorted(side="right"))
+    u = rs.random_sample()
+    p0 = np.float64(np.float32(1.0) / np.float32(n))
+    tot = np.float64(n) * p0
+    j = max(0, min(n, int(u * n)))
+    while j < n and (np.float64(j + 1) * p0) / tot <= u:
+        j += 1
+    while j > 0 and (np.float64(j) * p0) / tot > u:
+        j -= 1
+    center_id = min(j, n - 1)
+    centers[0] = xc[center_id]
+    indices[0] = center_id
+    closest = _pp_dist(centers[0], xc)
+    S = _pp_block_sums(closest)
+    W, G = _pp_scan(S)
+    pot = np.float32(G[-1])
+    for c in range(1, K):
+        rand_vals = rs.uniform(size=n_local_trials) * np.float64(pot)
+        cand = [_pp_search(closest, S, W, G, r) for r in rand_vals]
+        best = None
+        for t in range(n_local_trials):
+            d = np.minimum(closest, _pp_dist(xc[cand[t]], xc))
+            St = _pp_block_sums(d)
+            Wt, Gt = _pp_scan(St)
+            p = np.float32(Gt[-1])
+            if best is None or p < best[0]:
+                best = (p, t, d, St, Wt, Gt)
+        pot, t, closest, S, W, G = best
+        centers[c] = xc[cand[t]]
+        indices[c] = cand[t]
+    return centers, indices
+
+
+def kmeans_plusplus_fit(x, K, accum="B", random_state=None):
+    """KMeans(n_clusters=K).fit(x[:, None]) as utility.py:229-230 calls it (scikit-learn 1.7: init="k-means++",
+    n_init="auto" -> 1, max_iter=300, tol=1e-4, the global NumPy generator): mean-centre, seed, Lloyd."""
+    x = _f32c(x).ravel()
+    x_mean = np_mean(x)
+    xc = np.empty_like(x)
+    lib().orc_center_f32(_p(x, _f32p), x.size, x_mean, _p(xc, _f32p))
+    seeds, idx = kmeans_plusplus(xc, K, random_state)
+    # kmeans_lloyd subtracts the mean from its init in float32; hand it seeds + mean so that ... no: hand it the samples
+    # themselves (x[idx] - mean == xc[idx] bit for bit, the same float32 subtraction)
+    km = kmeans_lloyd(x, x[idx], accum=accum)
+    km.seed_indices_ = idx
+    return km

@@ -46,7 +46,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 
 def test_struct_layouts():
-    assert ctypes.sizeof(nat.KMeansParams) == 56
+    assert ctypes.sizeof(nat.KMeansParams) == 64
     assert ctypes.sizeof(nat.KMeansStatus) == 40
 
 

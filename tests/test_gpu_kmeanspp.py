@@ -1,0 +1,133 @@
+"""The reference's 4th initialisation mode on the GPU (run with -m gpu): get_quantized_weight(mode="kmeans++") =
+KMeans(n_clusters=2**bits).fit (neural_network_compression/common/utility.py:228-232).
+
+  * the device seeding (nnc_kmeanspp_seed_f32) against the oracle's restatement of scikit-learn's _kmeans_plusplus: the same
+    sample indices, bit for bit, from the same global-generator draws;
+  * the whole mode against the REFERENCE's own outputs (tests/golden/ref_kmeanspp.*, made by running the reference): NumPy's
+    global generator consumed exactly as scikit-learn consumes it, the same number of Lloyd iterations, centres within the
+    per-key bound below (scikit-learn's float32 running sums against the device's exact sums), centroid indices equal
+    wherever the bound on the histogram is 0.
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from neural_network_compression_amd import synth  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def util():
+    assert torch.cuda.is_available()
+    from neural_network_compression_amd import _native
+    from neural_network_compression_amd.common import utility
+
+    _native.load()
+    return utility
+
+
+@pytest.mark.parametrize("n,k", [(5, 4), (300, 4), (300, 32), (1000, 16), (1023, 8), (1024, 8), (1025, 8), (2560, 33), (30_000, 32),
+                                 (262_144, 16), (300_001, 64), (700_000, 257)])
+def test_seeding_equals_oracle(util, n, k):
+    w = synth.weights((n,), 9300 + n % 977)
+    if n > 2000:
+        w[np.abs(w) < 0.03] = 0          # a pruned vector: long runs of zero distance increments
+    x = torch.from_numpy(w).cuda()
+    mean = orc.np_mean(w)
+    xc = (w - mean).astype(np.float32)
+    for seed in (0, 5):
+        np.random.seed(seed)
+        want_c, want_i = orc.kmeans_plusplus(xc, k)
+        nxt_o = np.random.rand()
+        np.random.seed(seed)
+        seeds, ids = util.kmeans_plusplus_init(x, k)
+        nxt_d = np.random.rand()
+        assert nxt_o == nxt_d
+        assert np.array_equal(ids, want_i), (n, k, seed, int((ids != want_i).sum()))
+        assert np.array_equal(seeds, w[want_i])
+
+
+# key -> bound on max |centre - reference centre| / max |reference centre| where it exceeds 1e-6 (scikit-learn's float32
+# running sums; measured with the oracle's mode A <-> mode B gap), everything else: 1e-6 and identical centroid indices
+PP_BOUNDS = {
+    "kmeanspp/l300.dense1.w/bits2/seed0": 2.1e-6, "kmeanspp/l300.dense1.w/bits2/seed1": 2.1e-6,
+    "kmeanspp/l300.dense2.w/bits2/seed0": 1.3e-6, "kmeanspp/l300.dense2.w/bits2/seed1": 1.6e-6,
+    "kmeanspp/l300.dense2.w/bits5/seed1": 2.7e-5,
+    "kmeanspp/unpruned50k/bits2/seed0": 1.5e-6, "kmeanspp/unpruned50k/bits2/seed1": 1.7e-6,
+    "kmeanspp/unpruned50k/bits4/seed0": 1.6e-5, "kmeanspp/unpruned50k/bits4/seed1": 5.1e-5,
+    "kmeanspp/unpruned50k/bits5/seed0": 9.0e-6,
+}
+
+
+def _cases():
+    with open(os.path.join(HERE, "golden", "ref_kmeanspp.json")) as f:
+        man = json.load(f)
+    return man["cases"], np.load(os.path.join(HERE, "golden", "ref_kmeanspp.npz"))
+
+
+def _input(tname):
+    from tests.golden.make_goldens import lenet300_tensors, lenet5_tensors, q_for
+    if tname == "unpruned50k":
+        return synth.weights((50_000,), 6000)
+    table = {t[0]: t for t in lenet300_tensors() + lenet5_tensors()}
+    _, shape, seed = table[tname]
+    w = synth.weights(shape, seed)
+    orc.prune_weigth(w, q_for(tname), True)
+    return w
+
+
+def test_kmeanspp_mode_against_reference_goldens(util):
+    cases, arr = _cases()
+    keys = [k for k in sorted(cases) if not cases[k]["passthrough"]]
+    assert len(keys) >= 40 and set(PP_BOUNDS) <= set(keys)
+    exact_labels = 0
+    for key in keys:
+        c = cases[key]
+        w = _input(c["tensor"])
+        assert sha(w) == c["input_sha256"], key
+        np.random.seed(c["seed"])
+        q, km = util.get_quantized_weight(w.copy(), bits=c["bits"], mode="kmeans++")
+        assert float(np.random.rand()) == c["next_random"], key     # the global generator was consumed as scikit-learn consumes it
+        assert km.n_iter_ == c["n_iter"], (key, km.n_iter_, c["n_iter"])
+        gc = arr[c["centers"]]
+        err = np.max(np.abs(km.cluster_centers_.ravel().astype(np.float64) - gc)) / np.abs(gc).max()
+        assert err <= PP_BOUNDS.get(key, 1e-6), (key, err)
+        bc = np.bincount(km.labels_, minlength=c["K"])
+        l1 = int(np.abs(bc - arr[c["bincount"]]).sum())
+        if key not in PP_BOUNDS:
+            assert l1 == 0, (key, l1)
+        if sha(km.labels_) == c["labels_sha256"]:
+            exact_labels += 1
+        assert q.shape == w.shape and np.array_equal(q, km.cluster_centers_[km.labels_].reshape(w.shape))
+        # and bit for bit the oracle's order-independent mode from the same draws
+        np.random.seed(c["seed"])
+        ob = orc.kmeans_plusplus_fit(w.ravel(), c["K"], accum="B")
+        assert km.n_iter_ == ob.n_iter_ and np.array_equal(km.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), key
+        assert np.array_equal(km.labels_, ob.labels_), key
+    assert exact_labels >= len(keys) - len(PP_BOUNDS) - 4   # identical centroid indices nearly everywhere
+
+
+def test_kmeanspp_passthrough_and_device_input(util, capsys):
+    b = synth.weights((10,), 1)
+    q, km = util.get_quantized_weight(b, bits=4, mode="kmeans++")
+    assert km is None and q is b
+    assert "not enough bits: 10  vs  16" in capsys.readouterr().out
+    w = synth.weights((4096,), 77)
+    np.random.seed(3)
+    q1, km1 = util.get_quantized_weight(w.copy(), bits=3, mode="kmeans++")
+    np.random.seed(3)
+    q2, km2 = util.get_quantized_weight(torch.from_numpy(w.copy()).cuda(), bits=3, mode="kmeans++")
+    assert np.array_equal(q1, q2.cpu().numpy()) and np.array_equal(km1.cluster_centers_, km2.cluster_centers_)

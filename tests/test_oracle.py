@@ -250,3 +250,56 @@ def test_huffman_definition():
     assert list(lengths) == [0, 1, 0] and total == 7
     lengths, _, _ = orc.huffman_lengths([1, 1, 1, 1])
     assert list(lengths) == [2, 2, 2, 2]
+
+
+# ------------------------------------------------------------------ kmeans++ mode (utility.py:228-232)
+def _pp_goldens():
+    import json
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(d, "ref_kmeanspp.json")) as f:
+        man = json.load(f)
+    return man["cases"], np.load(os.path.join(d, "ref_kmeanspp.npz"))
+
+
+def _pp_input(tname):
+    from tests.golden.make_goldens import lenet300_tensors, lenet5_tensors, q_for
+    if tname == "unpruned50k":
+        return synth.weights((50_000,), 6000)
+    table = {t[0]: t for t in lenet300_tensors() + lenet5_tensors()}
+    _, shape, seed = table[tname]
+    w = synth.weights(shape, seed)
+    orc.prune_weigth(w, q_for(tname), True)
+    return w
+
+
+def test_kmeanspp_goldens_mode_a():
+    """The restated k-means++ seeding + Lloyd (mode A) against the REFERENCE's get_quantized_weight(mode="kmeans++")
+    outputs (tests/golden/make_goldens_kmeanspp.py): same consumption of NumPy's global generator in every case; the
+    same seeds, hence the same fit bit for bit, in all of these cases (the seeding's potential is a float32 BLAS dot in
+    scikit-learn and a float64 sum here: on long vectors a candidate may differ, see oracle.kmeans_plusplus)."""
+    cases, arr = _pp_goldens()
+    keys = [k for k in sorted(cases) if not cases[k]["passthrough"] and cases[k]["n"] <= 50_000]
+    assert len(keys) >= 30
+    for key in keys:
+        c = cases[key]
+        w = _pp_input(c["tensor"])
+        assert sha(w) == c["input_sha256"], key
+        np.random.seed(c["seed"])
+        km = orc.kmeans_plusplus_fit(w.ravel(), c["K"], accum="A")
+        assert float(np.random.rand()) == c["next_random"], key            # the generator was consumed as scikit-learn consumes it
+        assert km.n_iter_ == c["n_iter"], key
+        assert np.array_equal(km.cluster_centers_.ravel(), arr[c["centers"]]), key
+        assert sha(km.labels_) == c["labels_sha256"], key
+
+
+def test_kmeanspp_first_seed_closed_form_equals_numpy_choice():
+    """random_state.choice(n, p=w / w.sum()) with unit float32 weights, restated in closed form."""
+    for n in (2, 3, 10, 300, 1000, 30_000, 235_200):
+        w = np.ones(n, dtype=np.float32)
+        for seed in range(8):
+            rs = np.random.RandomState(seed)
+            want = rs.choice(n, p=w / w.sum())
+            np.random.seed(seed)
+            got = orc.kmeans_plusplus(np.arange(n, dtype=np.float32), 1)[1][0]
+            assert got == want, (n, seed)
