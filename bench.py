@@ -16,10 +16,13 @@ per-layer Deep-Compression pass on the data already resident in HBM:
 
 value = (weights processed by all ranks) / (time of the slowest rank) over exactly K steps.
 The JSON line also carries
-  roofline     : the Lloyd streaming kernel k_assign<accumulate> against the 8 TB/s HBM peak;
-                 algorithmic bytes = 4 B per weight per launch; its average duration is measured
-                 with HIP events around every launch inside the timed region (in-library, on the
-                 launching stream);
+  roofline     : the k-means assignment pass over the vector, k_assign<labels> (4 B read + centroid index + 4 B decoded
+                 value written per weight), against the 8 TB/s HBM peak; its duration is measured with HIP events
+                 around the launch inside the timed region (in-library, on the launching stream);
+  kernels      : the same for every data-touching kernel of the step (durations, launches per step, and -- for passes
+                 over the vector -- algorithmic bytes and achieved GB/s);
+  roofline_streaming_accumulate : the streaming form of the Lloyd pass (4 B read per weight per launch), which the
+                 iterations on a sorted vector no longer need, timed on its own after the timed region;
   cpu_baseline : the same pipeline through NumPy / scikit-learn on the host cores (rank 0, N = 1
                  only) on a bounded sample of the same vector.
 """
@@ -58,7 +61,7 @@ def parse():
                          "(BASELINE configs[3] read literally: one 25 M vector across 8 GPUs)")
     ap.add_argument("--python-exchange", action="store_true", help="N > 1: issue the per-iteration all-reduce from torch.distributed "
                                                                    "instead of inside the C library (nnc_kmeans_iterate_sharded)")
-    ap.add_argument("--dump-durations", action="store_true")
+    ap.add_argument("--no-streaming-leg", action="store_true", help="skip the separate timing of the streaming Lloyd pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path with all ranks on one GPU: --one-device)")
@@ -155,7 +158,7 @@ def main():
     res = step()  # set-up, not a warm-up step: first use loads the code objects, sizes the allocator pools, pins the host buffers
     for _ in range(args.warmup):
         res = step()
-    max_launches = 400 * max(1, args.steps)
+    max_launches = 1000 * max(1, args.steps)
     nat.check(L.nnc_profile_begin(max_launches))
     barrier()
     t0 = time.perf_counter()
@@ -164,9 +167,35 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ms_buf = (ctypes.c_float * max_launches)()
+    tag_buf = (ctypes.c_int32 * max_launches)()
     cnt = ctypes.c_int64(0)
-    nat.check(L.nnc_profile_end(ms_buf, max_launches, ctypes.byref(cnt)))
-    durs = np.array(ms_buf[: min(cnt.value, max_launches)], dtype=np.float64)
+    nat.check(L.nnc_profile_end(ms_buf, tag_buf, max_launches, ctypes.byref(cnt)))
+    nrec = min(cnt.value, max_launches)
+    all_ms = np.array(ms_buf[:nrec], dtype=np.float64)
+    all_tags = np.array(tag_buf[:nrec], dtype=np.int64)
+
+    # The streaming form of the Lloyd pass (k_assign<accumulate>: what an iteration costs on a vector that is NOT sorted, and
+    # the fallback of the rank-boundary form) timed on its own, outside the timed region: 30 launches on the same sorted
+    # 25 M vector with the converged centres.
+    stream_ms = np.zeros(0)
+    if rank == 0 and res.model is not None and not args.no_streaming_leg:
+        from neural_network_compression_amd import kmeans as _km
+
+        xq = w0.clone()
+        pipeline.prune_sharded_(xq, args.q, True, None)
+        km2 = _km.DeviceKMeans(xq, res.model.cluster_centers_.ravel(), rank_boundaries=False)
+        for _ in range(3):
+            nat.check(L.nnc_kmeans_accumulate(km2.x_iter.data_ptr(), km2.ws.data_ptr(), ctypes.byref(km2.p), km2.stream))
+        nat.check(L.nnc_profile_begin(64))
+        for _ in range(30):
+            nat.check(L.nnc_kmeans_accumulate(km2.x_iter.data_ptr(), km2.ws.data_ptr(), ctypes.byref(km2.p), km2.stream))
+        torch.cuda.synchronize(dev)
+        ms2 = (ctypes.c_float * 64)()
+        tg2 = (ctypes.c_int32 * 64)()
+        c2 = ctypes.c_int64(0)
+        nat.check(L.nnc_profile_end(ms2, tg2, 64, ctypes.byref(c2)))
+        stream_ms = np.array([ms2[i] for i in range(min(c2.value, 64)) if tg2[i] == 0], dtype=np.float64)
+        del km2, xq
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if group is not None:
@@ -175,23 +204,37 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     dt = float(tmax.item())
 
-    if rank == 0 and args.dump_durations:
-        print("launch durations (us):", " ".join(f"{v * 1e3:.0f}" for v in durs[: 60]), file=sys.stderr)
     if rank == 0:
+        n_loc = hi - lo
         n_iter = res.model.n_iter_ if res.model is not None else 0
-        # launches enqueued after convergence inside a batch return early (they still issue their first loads,
-        # about a third of a real launch): drop them
-        live = durs[durs > 0.6 * np.median(durs)] if durs.size else durs
-        avg_ms = float(live.mean()) if live.size else float("nan")
-        med_ms = float(np.median(live)) if live.size else float("nan")
-        achieved = 4.0 * (hi - lo) / (avg_ms * 1e-3) / 1e9 if live.size else float("nan")
+        k_fit = int(res.model.cluster_centers_.size) if res.model else 0
+        label_bytes = 1 if k_fit <= 256 else 2
+        # per-kernel durations over the timed region (HIP events on the launching stream, in-library)
+        names = {0: "k_assign<accumulate>", 1: "k_bounds", 2: "k_assign<labels>", 3: "k_threshold", 4: "k_chunk_sums", 5: "k_finalize",
+                 6: "k_prefix_blocks", 7: "k_minmax"}
+        # algorithmic bytes per weight and launch; None: not a pass over the vector
+        bpw = {0: 4, 1: None, 2: 4 + label_bytes + 4, 3: 9, 4: 4, 5: None, 6: 4, 7: 4}
+        kernels = {}
+        for tag, name in names.items():
+            d = all_ms[all_tags == tag]
+            if d.size == 0:
+                continue
+            live = d[d > 0.5 * np.median(d)] if tag in (0, 1, 5) else d   # launches enqueued behind a stop / pause return at once
+            ent = {"launches_per_step": d.size / args.steps, "avg_ms": float(live.mean()), "median_ms": float(np.median(live)),
+                   "ms_per_step": float(d.sum() / args.steps)}
+            if bpw[tag] is not None:
+                ent["algorithmic_bytes_per_launch"] = bpw[tag] * n_loc
+                ent["achieved_GBps"] = bpw[tag] * n_loc / (ent["avg_ms"] * 1e-3) / 1e9
+                ent["frac_of_hbm_peak"] = ent["achieved_GBps"] / HBM_PEAK_GBS
+            kernels[name] = ent
         traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tr_path):
             try:
-                traffic = json.load(open(tr_path)).get("k_assign_accumulate_hbm_bytes_per_launch")
+                traffic = json.load(open(tr_path)).get("k_assign_labels_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        lab = kernels.get("k_assign<labels>", {})
         out = {
             "metric": "weights/sec through prune+k-means (K=256)",
             "value": n_total * args.steps / dt,
@@ -203,26 +246,36 @@ def main():
             "config": {
                 "workload": f"configs[3]: synthetic {(hi - lo)/1e6:g} M fp32 weights per GPU ({n_total/1e6:g} M total), "
                             f"prune q={args.q} sigma -> CDF -> {args.mode}-init k-means bits={args.bits} "
-                            f"(K={res.model.cluster_centers_.size if res.model else 0}) to convergence -> labels+values -> Huffman lengths",
-                "weights_per_gpu": hi - lo, "exchange": ("rccl-in-library" if comm is not None else ("torch.distributed" if world > 1 else None)), "k": int(res.model.cluster_centers_.size) if res.model else 0,
-                "lloyd_iterations": int(n_iter), "stop": res.model.stop_reason_ if res.model else None,
+                            f"(K={k_fit}) to convergence -> labels+values -> Huffman lengths",
+                "weights_per_gpu": hi - lo, "exchange": ("rccl-in-library" if comm is not None else ("torch.distributed" if world > 1 else None)),
+                "k": k_fit, "lloyd_iterations": int(n_iter), "stop": res.model.stop_reason_ if res.model else None,
                 "relocations": int(res.model.n_relocations_) if res.model else 0,
+                "relocation_ties": int(getattr(res.model, "reloc_tie_", 0)) if res.model else 0,
                 "parallelism": f"shard{world}" if world > 1 else "single",
                 "weight_iterations_per_s": n_total * n_iter * args.steps / dt,
             },
+            # The k-means assignment pass over the whole vector (north_star's roofline kernel): E-step on the original order,
+            # centroid index + decoded value written per weight.  The Lloyd iterations themselves no longer stream the vector
+            # (rank-boundary form, k_bounds: O(K log N) reads per iteration), so they have no HBM roofline; their streaming
+            # form is reported in `roofline_streaming_accumulate`.
             "roofline": {
-                "bound": "hbm", "kernel": "k_assign<accumulate> (Lloyd E-step + per-cluster fixed-point sums)",
-                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if live.size else None,
+                "bound": "hbm", "kernel": "k_assign<labels> (final E-step: 4 B read + centroid index + 4 B decoded value written per weight)",
+                "achieved": lab.get("achieved_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": lab.get("frac_of_hbm_peak"),
                 "traffic": traffic,
-                "avg_kernel_ms": avg_ms, "launches_timed": int(live.size),
-                # the mean carries the four launches per step right after a mass relocation (dozens of centres crowded
-                # on the farthest samples: float32 cannot tell them apart, every one is evaluated); the typical launch:
-                "median_kernel_ms": med_ms,
-                "frac_median": (4.0 * (hi - lo) / (med_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if live.size else None,
-                "algorithmic_bytes_per_launch": 4 * (hi - lo),
+                "avg_kernel_ms": lab.get("avg_ms"), "launches_timed": int((all_tags == 2).sum()),
+                "algorithmic_bytes_per_launch": lab.get("algorithmic_bytes_per_launch"),
             },
+            "kernels": kernels,
         }
+        if stream_ms.size:
+            a = 4.0 * n_loc / (stream_ms.mean() * 1e-3) / 1e9
+            out["roofline_streaming_accumulate"] = {
+                "bound": "hbm", "kernel": "k_assign<accumulate> (streaming Lloyd pass, 4 B read per weight; off the timed path: 30 launches, converged centres)",
+                "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": a / HBM_PEAK_GBS,
+                "avg_kernel_ms": float(stream_ms.mean()), "median_kernel_ms": float(np.median(stream_ms)), "launches_timed": int(stream_ms.size),
+                "algorithmic_bytes_per_launch": 4 * n_loc,
+            }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, w_host)
         print(json.dumps(out))

@@ -408,14 +408,22 @@ int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void
                                          void *scratch_dev, size_t scratch_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
- * Measurement aid (used by bench.py): HIP events around every launch of the Lloyd streaming
- * kernel, recorded on the stream the kernel is launched on.
+ * Measurement aid (used by bench.py): HIP events around the launches of the data-touching kernels, recorded on the
+ * stream each kernel is launched on.
  * ---------------------------------------------------------------------------------- */
+#define NNC_PROF_ASSIGN_ACCUMULATE 0 /* k_assign<accumulate>: streaming Lloyd pass (vector in any order) */
+#define NNC_PROF_BOUNDS 1            /* k_bounds: rank-boundary Lloyd pass (sorted vector) */
+#define NNC_PROF_ASSIGN_LABELS 2     /* k_assign<labels>: final E-step, labels + values */
+#define NNC_PROF_THRESHOLD 3         /* k_threshold: mask + zero in place */
+#define NNC_PROF_CHUNK_SUMS 4        /* k_chunk_sums: NumPy-exact chunk sums (two passes per sigma) */
+#define NNC_PROF_FINALIZE 5          /* k_finalize (K-sized) */
+#define NNC_PROF_PREFIX 6            /* k_prefix_blocks */
+#define NNC_PROF_MINMAX 7            /* k_minmax */
 int nnc_profile_begin(int32_t max_launches);
-/* Waits for the recorded events; ms_out[i] = duration in ms of the i-th timed launch (launch
- * order), up to cap entries; count_out = launches timed.  Launches enqueued after the state
- * machine had stopped return at once and show up as very short entries. */
-int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out);
+/* Waits for the recorded events; ms_out[i] / tags_out[i] = duration in ms and NNC_PROF_* tag of the i-th timed launch
+ * (launch order), up to cap entries; count_out = launches timed.  Launches enqueued after the state machine had stopped
+ * return at once and show up as very short entries. */
+int nnc_profile_end(float *ms_out, int32_t *tags_out, int64_t cap, int64_t *count_out);
 
 #ifdef NNC_DIAG
 /* Diagnostics: exported only by a library built with -DNNC_DIAG (libnnc_hip_diag.so, tools/); the product library has
@@ -437,6 +445,32 @@ int nnc_debug_reloc_fail(void *ws, int32_t *host_out);
  * definition is in DESIGN.md.  lengths_out[k]; hist_out[65] (hist_out[l] = symbols of length l). */
 int nnc_huffman_lengths(const int64_t *counts, int32_t k, uint8_t *lengths_out, int64_t *hist_out,
                         int64_t *total_bits_out);
+
+/* ------------------------------------------------------------------------------------
+ * Compressed form of a quantized layer: the centroid indices as a canonical-Huffman bit stream (Deep Compression's third
+ * stage; named by the reference, README.md:9, never implemented).  Built from what the path already has: indices
+ * (nnc_kmeans_assign), histogram (nnc_kmeans_label_counts / nnc_bincount), code lengths (nnc_huffman_lengths).
+ *   nnc_huffman_codes        (host)  canonical codes from code lengths <= 32 bits (symbols ordered by (length, symbol))
+ *   nnc_huffman_chunk_offsets        bit offset of every chunk of NNC_CODEC_CHUNK indices: chunk_off_dev[nchunks + 1] uint64,
+ *                                    chunk_off_dev[nchunks] = total bits   (nchunks = nnc_codec_chunks(n))
+ *   nnc_huffman_encode               words_dev[nwords] (uint32, zeroed here; nwords >= total_bits / 32 + 2), MSB first
+ *   nnc_huffman_decode_tables (host) first-code / count / first-index per length + symbols by (length, symbol), packed into
+ *                                    nnc_huffman_decode_tables_bytes() bytes; copy them to the device for
+ *   nnc_huffman_decode               one thread per chunk; *bad_dev = 1 if a chunk does not parse to its recorded length
+ * The pruned zeros share one centroid, so their index is the most frequent symbol and costs one bit: the dense index stream
+ * plays the role of Deep Compression's relative-index sparse format without a separate position stream.
+ * ---------------------------------------------------------------------------------- */
+#define NNC_CODEC_CHUNK 1024
+int nnc_huffman_codes(const uint8_t *lengths, int32_t k, uint32_t *codes_out);
+size_t nnc_codec_chunks(int64_t n);
+int nnc_huffman_chunk_offsets(const void *labels, int label_bytes, int64_t n, const uint8_t *lengths_dev, int32_t k,
+                              uint64_t *chunk_off_dev, void *stream);
+int nnc_huffman_encode(const void *labels, int label_bytes, int64_t n, const uint32_t *codes_dev, const uint8_t *lengths_dev, int32_t k,
+                       const uint64_t *chunk_off_dev, uint32_t *words_dev, int64_t nwords, void *stream);
+size_t nnc_huffman_decode_tables_bytes(void);
+int nnc_huffman_decode_tables(const uint8_t *lengths, int32_t k, void *tables_out, size_t tables_bytes);
+int nnc_huffman_decode(const uint32_t *words_dev, const uint64_t *chunk_off_dev, int64_t n, const void *tables_dev, int32_t k,
+                       void *labels_out, int label_bytes, int32_t *bad_dev, void *stream);
 
 #ifdef __cplusplus
 }

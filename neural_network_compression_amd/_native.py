@@ -107,6 +107,13 @@ SIGNATURES = {
     "nnc_kmeanspp_seed_f32": (c_int, [c_void_p, c_i64, c_f32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_centroid_grad_f32": (c_int, [c_void_p, c_void_p, c_int, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "nnc_gather_f32": (c_int, [c_void_p, c_i32, c_void_p, c_int, c_i64, c_void_p, c_void_p]),
+    "nnc_huffman_codes": (c_int, [ctypes.POINTER(ctypes.c_uint8), c_i32, ctypes.POINTER(ctypes.c_uint32)]),
+    "nnc_codec_chunks": (c_size, [c_i64]),
+    "nnc_huffman_chunk_offsets": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_i32, c_void_p, c_void_p]),
+    "nnc_huffman_encode": (c_int, [c_void_p, c_int, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_i64, c_void_p]),
+    "nnc_huffman_decode_tables_bytes": (c_size, []),
+    "nnc_huffman_decode_tables": (c_int, [ctypes.POINTER(ctypes.c_uint8), c_i32, c_void_p, c_size]),
+    "nnc_huffman_decode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_int, c_void_p, c_void_p]),
     "nnc_comm_unique_id": (c_int, [c_void_p, c_size]),
     "nnc_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_size, c_i32, c_i32]),
     "nnc_comm_destroy": (c_int, [c_void_p]),
@@ -119,7 +126,7 @@ SIGNATURES = {
     "nnc_kmeans_reloc_scratch_bytes_sharded": (c_size, [c_i32, c_i32, c_i32]),
     "nnc_kmeans_relocate_windowed_sharded": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p]),
     "nnc_profile_begin": (c_int, [c_i32]),
-    "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), c_i64, ctypes.POINTER(c_i64)]),
+    "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), ctypes.POINTER(c_i32), c_i64, ctypes.POINTER(c_i64)]),
     "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
 }
 

@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 DIAG = os.environ.get("NNC_DIAG", "0") not in ("", "0")   # diagnostics build (phase traces, ablated kernels): tools/ only
 LIB = os.path.join(CSRC, "libnnc_hip_diag.so" if DIAG else "libnnc_hip.so")
-SOURCES = [os.path.join(CSRC, "nnc_hip.hip"), os.path.join(CSRC, "nnc_sort.hip"), os.path.join(CSRC, "nnc_pp.hip")]
+SOURCES = [os.path.join(CSRC, "nnc_hip.hip"), os.path.join(CSRC, "nnc_sort.hip"), os.path.join(CSRC, "nnc_pp.hip"), os.path.join(CSRC, "nnc_codec.hip")]
 EXTRA_LIBS: list = []
 
 
@@ -42,7 +42,7 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17",
         "-ffp-contract=off",  # the reference arithmetic is unfused float32; never contract
         "-fPIC", "-shared", "-I", INCLUDE, "-o", tmp,
-    ] + (["-DNNC_DIAG"] if DIAG else []) + SOURCES + EXTRA_LIBS
+    ] + (["-DNNC_DIAG"] if DIAG else []) + (["-DNNC_NO_HELP"] if os.environ.get("NNC_NO_HELP") else []) + SOURCES + EXTRA_LIBS
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         if os.path.exists(tmp):

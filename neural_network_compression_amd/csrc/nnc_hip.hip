@@ -93,6 +93,72 @@ extern "C" int nnc_device_info(char *arch_out, size_t arch_len, int *cu_count_ou
 static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
 
 // --------------------------------------------------------------------------------------
+// optional in-library profiler: HIP events around the launches of the data-touching kernels, on the
+// stream each kernel is launched on (hipExtLaunchKernelGGL stamps the events at the kernel's own begin
+// and end, not at the command processor's arrival, so the difference is the launch's execution time).
+// bench.py turns it on to report per-kernel durations over the timed region.
+// --------------------------------------------------------------------------------------
+struct ProfRec { hipEvent_t a, b; int tag; };
+static std::mutex g_prof_mu;            // the pool is shared by every calling thread
+static std::vector<ProfRec> g_prof_pool;
+static size_t g_prof_used = 0;
+static std::atomic<bool> g_prof_on{false};
+static int64_t g_prof_skipped = 0;
+
+static void prof_take(int tag, hipEvent_t *a, hipEvent_t *b)
+{
+    *a = nullptr; *b = nullptr;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    if (g_prof_on && g_prof_used < g_prof_pool.size()) { ProfRec &r = g_prof_pool[g_prof_used++]; r.tag = tag; *a = r.a; *b = r.b; }
+    else g_prof_skipped++;
+}
+#define NNC_LAUNCH_PROF(tag, kernel, grid, block, lds, stream, ...)                                   \
+    do {                                                                                               \
+        hipEvent_t ea_, eb_;                                                                           \
+        prof_take(tag, &ea_, &eb_);                                                                    \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ea_, eb_, 0, __VA_ARGS__);             \
+    } while (0)
+
+extern "C" int nnc_profile_begin(int32_t max_launches)
+{
+    if (max_launches < 1) return fail(NNC_EINVAL, "nnc_profile_begin: max_launches < 1");
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    while ((int64_t)g_prof_pool.size() < max_launches) {
+        ProfRec pr;
+        pr.tag = -1;
+        HIPCHK(hipEventCreate(&pr.a));
+        HIPCHK(hipEventCreate(&pr.b));
+        g_prof_pool.push_back(pr);
+    }
+    g_prof_used = 0;
+    g_prof_skipped = 0;
+    g_prof_on = true;
+    return NNC_OK;
+}
+
+// Waits for the recorded events and copies the duration (ms) and the NNC_PROF_* tag of each timed launch, in launch
+// order, into ms_out / tags_out[0..cap); count_out = number of launches timed.
+extern "C" int nnc_profile_end(float *ms_out, int32_t *tags_out, int64_t cap, int64_t *count_out)
+{
+    g_prof_on = false;
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    int64_t cnt = 0;
+    for (size_t i = 0; i < g_prof_used; i++) {
+        HIPCHK(hipEventSynchronize(g_prof_pool[i].b));
+        float ms = 0.0f;
+        HIPCHK(hipEventElapsedTime(&ms, g_prof_pool[i].a, g_prof_pool[i].b));
+        if (ms_out && cnt < cap) ms_out[cnt] = ms;
+        if (tags_out && cnt < cap) tags_out[cnt] = g_prof_pool[i].tag;
+        cnt++;
+    }
+    if (count_out) *count_out = cnt;
+    g_prof_used = 0;
+    return NNC_OK;
+}
+
+
+// --------------------------------------------------------------------------------------
 // small device helpers
 // --------------------------------------------------------------------------------------
 #define WAVE 64
@@ -231,11 +297,11 @@ extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const fl
         int64_t cap = (int64_t)cu_count() * 8;
         int grid = (int)std::min<int64_t>(blocks, cap) + (tail > 0 ? 1 : 0);
         if (sqdev) {
-            if (vec) hipLaunchKernelGGL((k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
-            else hipLaunchKernelGGL((k_chunk_sums<true, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
+            if (vec) NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
+            else NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<true, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
         } else {
-            if (vec) hipLaunchKernelGGL((k_chunk_sums<false, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
-            else hipLaunchKernelGGL((k_chunk_sums<false, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
+            if (vec) NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<false, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
+            else NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<false, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
         }
         LAUNCHCHK("k_chunk_sums");
     }
@@ -356,8 +422,8 @@ extern "C" int nnc_threshold_mask_f32(float *x, int64_t n, const float *thr_dev,
     if (n == 0) return NNC_OK;
     const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
     int grid = stream_grid((n + 3) / 4, 256, 4);
-    if (vec) hipLaunchKernelGGL((k_threshold<true>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
-    else hipLaunchKernelGGL((k_threshold<false>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
+    if (vec) NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold<true>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
+    else NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold<false>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
     LAUNCHCHK("k_threshold");
     return NNC_OK;
 }
@@ -538,8 +604,8 @@ static int minmax_impl(const float *x, int64_t n, int skip_zeros, float *out_dev
     int grid = minmax_grid(n);
     MinMaxPartial *part = reinterpret_cast<MinMaxPartial *>(ws);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (vec) hipLaunchKernelGGL((k_minmax<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
-    else hipLaunchKernelGGL((k_minmax<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
+    if (vec) NNC_LAUNCH_PROF(NNC_PROF_MINMAX, (k_minmax<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
+    else NNC_LAUNCH_PROF(NNC_PROF_MINMAX, (k_minmax<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
     LAUNCHCHK("k_minmax");
     hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, out_dev, reinterpret_cast<long long *>(count_dev),
                        reinterpret_cast<long long *>(signs_dev));
@@ -1337,8 +1403,8 @@ __device__ __forceinline__ void km_shard_add(KmWs *ws, int p, long long sum, uns
 }
 
 // exact labels of the samples [s, e) whose candidates are the centres plo .. phi (value order), added to the sums
-__device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, long long s, long long e, int plo, int phi, const KmTab *__restrict__ tab,
-                                                KmWs *ws, float mean, int Sft, int lane)
+__device__ __attribute__((noinline)) void km_bounds_range(const float *__restrict__ xs, long long s, long long e, int plo, int phi, const KmTab *__restrict__ tab,
+                                                        KmWs *ws, float mean, int Sft, int lane)
 {
     s = uni_ll(s); e = uni_ll(e); plo = uni_i(plo); phi = uni_i(phi);
     if (phi <= plo) { // (cannot happen for an undecided stretch; kept total: everything is plo's)
@@ -1400,6 +1466,13 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
         run_s += fix_f32(xc, Sft);
     }
     if (run_n) km_shard_add(ws, run_p, run_s, run_n);
+}
+
+__device__ __forceinline__ int km_claim(int *counter, int lane)
+{
+    int t = 0;
+    if (lane == 0) t = atomicAdd(counter, 1);
+    return uni_i(t);
 }
 
 __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
@@ -1506,16 +1579,13 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
         if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
         const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
         const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
-        const long long ntiles = (e - s + KM_TILE - 1) / KM_TILE;
-        for (;;) {
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&ws->q_next[r], 1);
-            t = uni_i(t);
-            KBSTAMP(16 * j + 6, 1000 + t);
-            if (t >= ntiles) break;
+        const int ntiles = (int)((e - s + KM_TILE - 1) / KM_TILE);
+        int t = km_claim(&ws->q_next[r], lane);
+        while (t < ntiles) {
             const long long ts = s + (long long)t * KM_TILE;
             const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
             km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
+            t = km_claim(&ws->q_next[r], lane);
         }
     }
     KBSTAMP(16 * j + 11, 0xE0D);
@@ -2096,7 +2166,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
     nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
-#define KM_LAUNCH_FIN(NT, FUSED, THREADS) hipLaunchKernelGGL((k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket)
+#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket)
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
     else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256);
@@ -2198,53 +2268,6 @@ static int km_grid(int64_t n, size_t lds_bytes)
     return (int)std::min<int64_t>(blocks, (int64_t)cu_count() * per_cu * mult_q / 4);
 }
 
-// --------------------------------------------------------------------------------------
-// optional in-library profiler: HIP events around every launch of the Lloyd streaming
-// kernel (k_assign<accumulate>), on the stream the kernel is launched on.  bench.py turns it
-// on to report the kernel's average duration over the timed region.
-// --------------------------------------------------------------------------------------
-struct ProfPair { hipEvent_t a, b; };
-static std::mutex g_prof_mu;            // the pool is shared by every calling thread
-static std::vector<ProfPair> g_prof_pool;
-static size_t g_prof_used = 0;
-static std::atomic<bool> g_prof_on{false};
-static int64_t g_prof_skipped = 0;
-
-extern "C" int nnc_profile_begin(int32_t max_launches)
-{
-    if (max_launches < 1) return fail(NNC_EINVAL, "nnc_profile_begin: max_launches < 1");
-    std::lock_guard<std::mutex> lock(g_prof_mu);
-    while ((int64_t)g_prof_pool.size() < max_launches) {
-        ProfPair pp;
-        HIPCHK(hipEventCreate(&pp.a));
-        HIPCHK(hipEventCreate(&pp.b));
-        g_prof_pool.push_back(pp);
-    }
-    g_prof_used = 0;
-    g_prof_skipped = 0;
-    g_prof_on = true;
-    return NNC_OK;
-}
-
-// Waits for the recorded events and copies the duration (ms) of each timed launch, in launch
-// order, into ms_out[0..cap); count_out = number of launches timed.
-extern "C" int nnc_profile_end(float *ms_out, int64_t cap, int64_t *count_out)
-{
-    g_prof_on = false;
-    std::lock_guard<std::mutex> lock(g_prof_mu);
-    int64_t cnt = 0;
-    for (size_t i = 0; i < g_prof_used; i++) {
-        HIPCHK(hipEventSynchronize(g_prof_pool[i].b));
-        float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, g_prof_pool[i].a, g_prof_pool[i].b));
-        if (ms_out && cnt < cap) ms_out[cnt] = ms;
-        cnt++;
-    }
-    if (count_out) *count_out = cnt;
-    g_prof_used = 0;
-    return NNC_OK;
-}
-
 #ifdef NNC_DIAG
 // diagnostic: shader clock = d(s_memtime) / d(s_memrealtime) * 100 MHz over a VALU spin loop
 __global__ void k_debug_clock(int iters, float *out)
@@ -2299,7 +2322,7 @@ extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_p
     const long long nblk = (p->n + KM_PB - 1) / KM_PB;
     long long *pb = reinterpret_cast<long long *>(prefix_dev);
     const int grid = (int)std::max<long long>(1, std::min<long long>((nblk + 3) / 4, (long long)cu_count() * 8));
-    hipLaunchKernelGGL(k_prefix_blocks, dim3(grid), dim3(256), 0, S(stream), x_sorted, (long long)p->n, p->x_mean, p->fix_shift, pb);
+    NNC_LAUNCH_PROF(NNC_PROF_PREFIX, k_prefix_blocks, dim3(grid), dim3(256), 0, S(stream), x_sorted, (long long)p->n, p->x_mean, p->fix_shift, pb);
     LAUNCHCHK("k_prefix_blocks");
     hipLaunchKernelGGL(k_prefix_scan, dim3(1), dim3(KM_THREADS), 0, S(stream), pb, nblk);
     LAUNCHCHK("k_prefix_scan");
@@ -2313,7 +2336,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     if (p->prefix_dev && p->n > 0) {
         if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
         const int grid = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
-        hipLaunchKernelGGL(k_bounds, dim3(grid), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev));
+        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(grid), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev));
         LAUNCHCHK("k_bounds");
         return NNC_OK;
     }
@@ -2325,12 +2348,8 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     if (p->n == 0) return NNC_OK;
     // hipExtLaunchKernelGGL stamps the events at the kernel's own begin and end (not at the
     // command processor's arrival), so the difference is the launch's execution time
-    hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    if (g_prof_on.load(std::memory_order_relaxed)) {
-        std::lock_guard<std::mutex> lock(g_prof_mu);
-        if (g_prof_on && g_prof_used < g_prof_pool.size()) { ev_a = g_prof_pool[g_prof_used].a; ev_b = g_prof_pool[g_prof_used].b; g_prof_used++; }
-        else g_prof_skipped++;
-    }
+    hipEvent_t ev_a, ev_b;
+    prof_take(NNC_PROF_ASSIGN_ACCUMULATE, &ev_a, &ev_b);
 #define KM_LAUNCH_ACC(...) hipExtLaunchKernelGGL((k_assign<0, __VA_ARGS__>), dim3(grid), dim3(KM_THREADS), lds, S(stream), ev_a, ev_b, 0, x, p->n, w, which, (uint8_t *)nullptr, (float *)nullptr, (float *)nullptr, (unsigned long long *)nullptr, (const int *)nullptr)
     if (false) {}
 #ifdef NNC_DIAG
@@ -2548,11 +2567,11 @@ static int km_assign(const float *x, void *ws, const nnc_kmeans_params *pp, int 
     unsigned long long *dh = reinterpret_cast<unsigned long long *>(dist_hist4096_dev);
     if (dh) HIPCHK(hipMemsetAsync(dh, 0, 4096 * sizeof(int64_t), S(stream)));
     if (label_bytes == 2) {
-        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh, n_dev);
-        else hipLaunchKernelGGL((k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh, n_dev);
+        if (vec) NNC_LAUNCH_PROF(NNC_PROF_ASSIGN_LABELS, (k_assign<1, true, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh, n_dev);
+        else NNC_LAUNCH_PROF(NNC_PROF_ASSIGN_LABELS, (k_assign<1, false, uint16_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint16_t *>(labels_out), quant_out, dist_out, dh, n_dev);
     } else {
-        if (vec) hipLaunchKernelGGL((k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh, n_dev);
-        else hipLaunchKernelGGL((k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh, n_dev);
+        if (vec) NNC_LAUNCH_PROF(NNC_PROF_ASSIGN_LABELS, (k_assign<1, true, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh, n_dev);
+        else NNC_LAUNCH_PROF(NNC_PROF_ASSIGN_LABELS, (k_assign<1, false, uint8_t>), dim3(grid), dim3(KM_THREADS), lds, S(stream), x, p.n, w, which, reinterpret_cast<uint8_t *>(labels_out), quant_out, dist_out, dh, n_dev);
     }
     LAUNCHCHK("k_assign<labels>");
     return NNC_OK;
