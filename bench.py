@@ -61,6 +61,7 @@ def parse():
                          "(BASELINE configs[3] read literally: one 25 M vector across 8 GPUs)")
     ap.add_argument("--python-exchange", action="store_true", help="N > 1: issue the per-iteration all-reduce from torch.distributed "
                                                                    "instead of inside the C library (nnc_kmeans_iterate_sharded)")
+    ap.add_argument("--dump-durations", action="store_true", help="stderr: the per-launch durations (us) of the iteration kernels of the last step")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the separate timing of the streaming Lloyd pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
@@ -204,6 +205,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     dt = float(tmax.item())
 
+    if rank == 0 and args.dump_durations:
+        per = nrec // max(1, args.steps)
+        seq = [(int(t), float(m) * 1e3) for t, m in zip(all_tags[-per:], all_ms[-per:])]
+        print("last step, launch order (tag:us): " + " ".join(f"{t}:{u:.0f}" for t, u in seq), file=sys.stderr)
     if rank == 0:
         n_loc = hi - lo
         n_iter = res.model.n_iter_ if res.model is not None else 0

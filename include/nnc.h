@@ -232,7 +232,9 @@ int nnc_kmeans_status_async(void *ws, nnc_kmeans_status *host_out, void *stream)
  * the host polls that word until it reads its ticket, then reads the status. */
 int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t ticket, void *stream);
 /* nnc_kmeans_iterate with the look-in attached to the last launch of the batch (no launch of its
- * own): status block and ticket are written to host_mapped as by nnc_kmeans_status_publish. */
+ * own): status block and ticket are written to host_mapped as by nnc_kmeans_status_publish.
+ * With few centres (k <= 64) on a sorted vector with prefix sums (p->prefix_dev) both run the whole batch as ONE launch of
+ * one workgroup that iterates until the fit stops, pauses or `iters` iterations are through: pass max_iter and look once. */
 int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params *p, int32_t iters, void *host_mapped,
                                uint64_t ticket, void *stream);
 int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream);

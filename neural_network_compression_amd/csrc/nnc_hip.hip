@@ -1475,16 +1475,11 @@ __device__ __forceinline__ int km_claim(int *counter, int lane)
     return uni_i(t);
 }
 
-__global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
+// wave j's share of one rank-boundary pass (see above): centre j's certain stretch and the undecided stretch above it
+__device__ __forceinline__ void km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
+                                               const KmTab *__restrict__ tab, const int ku, const float mean, const int Sft,
                                                const long long *__restrict__ pblk)
 {
-    const int lane = threadIdx.x & 63;
-    const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (!(which & 2) && (ws->st.done | ws->st.paused)) return; // (which & 2: counting pass after the fit)
-    const KmTab *__restrict__ tab = &ws->tab[ws->cur ^ (which & 1)];
-    const int ku = tab->ku;
-    const float mean = ws->p.x_mean;
-    const int Sft = ws->p.fix_shift;
     if (j < ku) {
         // ---- the zone ends that bound this wave's stretches
         double Uj = -INFINITY, Ujm1 = -INFINITY, Lj = INFINITY;
@@ -1563,6 +1558,12 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
             } else km_bounds_range(xs, s, b, j, phi, tab, ws, mean, Sft, lane);
         }
     }
+}
+
+// tiles of long undecided stretches: every wave that comes through here helps
+__device__ __forceinline__ void km_bounds_help(const int j, const int lane, const float *__restrict__ xs, KmWs *__restrict__ ws,
+                                               const KmTab *__restrict__ tab, const float mean, const int Sft)
+{
     // ---- tiles of long undecided stretches: every wave of the launch helps; the publisher itself comes through here after its
     // own record is out, so every tile is taken by somebody who is still running
     int nrec = 0;
@@ -1588,6 +1589,20 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
             t = km_claim(&ws->q_next[r], lane);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
+                                               const long long *__restrict__ pblk)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (!(which & 2) && (ws->st.done | ws->st.paused)) return; // (which & 2: counting pass after the fit)
+    const KmTab *__restrict__ tab = &ws->tab[ws->cur ^ (which & 1)];
+    const int ku = tab->ku;
+    const float mean = ws->p.x_mean;
+    const int Sft = ws->p.fix_shift;
+    km_bounds_wave(j, lane, xs, n, ws, tab, ku, mean, Sft, pblk);
+    km_bounds_help(j, lane, xs, ws, tab, mean, Sft);
     KBSTAMP(16 * j + 11, 0xE0D);
 }
 
@@ -2103,6 +2118,41 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
     }
 }
 
+// A whole batch of Lloyd iterations in ONE launch, for fits with few centres on a sorted vector (k <= KM_FUSE_KMAX, rank-boundary
+// form): one workgroup; per iteration its sixteen waves locate the cluster boundaries and add up the sums (km_bounds_wave), then
+// the first wave runs the finalize body; until the fit stops, pauses (an empty cluster: the host relocates) or `iters`
+// iterations are through.  What the two-launch form pays per iteration in launches and kernel boundaries (a third of the time
+// of a short layer's fit) is a workgroup barrier and a cache fence here.  The look-in rides on the launch.
+__global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws,
+                                                         const long long *__restrict__ pblk, int iters, nnc_kmeans_status *host_st,
+                                                         unsigned long long *host_ticket, unsigned long long ticket)
+{
+    __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX];
+    __shared__ int fin_kc[2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = uni_i(tid >> 6);
+    const float mean = ws->p.x_mean;
+    const int Sft = ws->p.fix_shift;
+    for (int it = 0; it < iters; it++) {
+        // (everything below reads what the first wave wrote in the previous round: the fence + barrier pair at the end of a
+        // round writes its stores through and drops this CU's cached copies)
+        if (ws->st.done | ws->st.paused) break; // the same for every thread
+        const KmTab *tab = &ws->tab[ws->cur];
+        const int ku = tab->ku;
+        for (int j = wv; j < ku; j += KM_THREADS / 64) km_bounds_wave(j, lane, xs, n, ws, tab, ku, mean, Sft, pblk);
+        km_bounds_help(wv, lane, xs, ws, tab, mean, Sft);
+        __threadfence();
+        __syncthreads();
+        if (tid < 64) km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc);
+        __threadfence();
+        __syncthreads();
+    }
+    if (host_st && tid == 0) {
+        *host_st = ws->st;
+        __threadfence_system();
+        *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
+    }
+}
+
 // cell g -> candidate range [first p with gc[p] >= g, last p with hc[p] <= g] (both monotone in g);
 // one cell per thread.  The first and last cells are open-ended: everything below lo / above hi
 // is clamped into them.
@@ -2141,10 +2191,16 @@ static bool km_fused(const nnc_kmeans_params *p)
     return p->k <= KM_FUSE_KMAX && glog2 <= KM_FUSE_GLOG2;
 }
 
+// few centres on a sorted vector with prefix sums: whole batches of iterations run as one launch of one workgroup (k_fit_small)
+static bool km_one_launch_fit(const nnc_kmeans_params *p, const float *x)
+{
+    return p->prefix_dev && p->n > 0 && p->n == p->n_total && km_fused(p) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
 // The cell table of tab[cur ^ which], for the kernels that look samples up, when the iterations did not keep it current.
 static int km_ensure_cells(KmWs *w, const nnc_kmeans_params *p, int which, void *stream)
 {
-    if (!p->prefix_dev || km_fused(p)) return NNC_OK; // streaming iterations keep it current; few centres: k_finalize builds it
+    if (!p->prefix_dev) return NNC_OK; // streaming iterations keep it current
     hipLaunchKernelGGL(k_cells_prepare, dim3(1), dim3(1), 0, S(stream), w, which);
     LAUNCHCHK("k_cells_prepare");
     hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, (nnc_kmeans_status *)nullptr,
@@ -2422,6 +2478,13 @@ extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_par
     if (p.n != p.n_total) return fail(NNC_EINVAL, "nnc_kmeans_iterate: sharded vector (n != n_total) needs accumulate / all-reduce / finalize");
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if (km_one_launch_fit(&p, x)) {
+        if (iters < 1) return NNC_OK;
+        hipLaunchKernelGGL(k_fit_small, dim3(1), dim3(KM_THREADS), 0, S(stream), x, (long long)p.n, w, reinterpret_cast<const long long *>(p.prefix_dev),
+                           (int)iters, (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull);
+        LAUNCHCHK("k_fit_small");
+        return NNC_OK;
+    }
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
         if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream))) return rc;
@@ -2481,6 +2544,14 @@ extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_km
         return fail(NNC_EINVAL, "nnc_kmeans_iterate_publish: iters < 1, or null / unaligned host pointer");
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if (km_one_launch_fit(&p, x)) {
+        unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
+        hipLaunchKernelGGL(k_fit_small, dim3(1), dim3(KM_THREADS), 0, S(stream), x, (long long)p.n, w, reinterpret_cast<const long long *>(p.prefix_dev),
+                           (int)iters, reinterpret_cast<nnc_kmeans_status *>(hb), reinterpret_cast<unsigned long long *>(hb + sizeof(nnc_kmeans_status)),
+                           (unsigned long long)ticket);
+        LAUNCHCHK("k_fit_small");
+        return NNC_OK;
+    }
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
         const bool last = i == iters - 1;

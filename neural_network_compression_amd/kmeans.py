@@ -263,6 +263,9 @@ class DeviceKMeans:
             self.prefix = torch.empty(int(self.L.nnc_kmeans_prefix_bytes(n)), dtype=torch.uint8, device=self.dev)
             nat.check(self.L.nnc_kmeans_prefix_build(self.x_iter.data_ptr(), ctypes.byref(self.p), self.prefix.data_ptr(), self.stream))
             self.p.prefix_dev = self.prefix.data_ptr()
+        # few centres on one GPU: the library runs a whole batch of iterations as ONE launch that stops by itself at
+        # convergence or at an empty cluster (include/nnc.h, nnc_kmeans_iterate_publish), so there is nothing to size
+        self.one_launch = self.prefix is not None and group is None and self.k <= 64 and int(grid_log2) <= 11
 
     # -------------------------------------------------------------- low-level steps
     def publish(self) -> int:
@@ -500,7 +503,7 @@ class DeviceKMeans:
         """Runs to convergence.  Returns (QuantizedModel, values tensor or None) where
         values = cluster_centers_[labels_] as a device float32 vector (utility.py:239)."""
         strict_labels = None
-        batch = 1  # the first iteration is where duplicate initial centres surface as empty clusters
+        batch = MAX_ITER if self.one_launch else 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
         while True:
             st = self.iterate_and_look(batch)
@@ -511,12 +514,14 @@ class DeviceKMeans:
                 # iteration on the device, then go on one iteration at a time for a while.  No look-in
                 # in between: if the resumed iteration was the last one the next launch is a no-op.
                 self._relocate_and_resume(st)
-                batch = 1
+                batch = MAX_ITER if self.one_launch else 1
                 hist = []
                 continue
             # size the next batch so that it ends about where the shift crosses the tolerance
             # (launches enqueued after convergence are no-ops, but they still cost a dispatch)
             hist.append((int(st.iter), float(st.shift_tot)))
+            if self.one_launch:
+                continue
             batch = min(self.batch, batch * 2)
             if len(hist) >= 2 and hist[-1][1] > 0 and hist[-2][1] > hist[-1][1] and self.tol_ > 0:
                 (i0, s0), (i1, s1) = hist[-2], hist[-1]
