@@ -808,6 +808,7 @@ struct KmWs {
     // k_bounds: long stretches of samples whose cluster float32 cannot tell from the zones alone, cut into tiles any wave
     // may take (two self-validating words per record, see k_bounds); emptied by the kernel that consumes the sums
     int32_t q_n, q_pad;
+    long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
     int32_t q_next[NNC_KMAX];
     KmTab tab[2];
@@ -1447,23 +1448,35 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
         KBSTAMP(16 * plo + 5, 0xD0E);
         return;
     }
-    // three or more centres within rounding distance of each other: the general scan, one run of equal winners at a time
+    // three or more centres within rounding distance of each other: the general scan, one run of equal winners at a time.  The
+    // candidates sit in the lanes' registers (lane l holds centre plo + l of the current group of 64) and go round by readlane.
     int run_p = -1;
     unsigned run_n = 0;
     long long run_s = 0;
-    for (long long i = s + lane; i < e; i += 64) {
-        const float xc = xs[i] - mean;
-        float2 cc = tab->cand[plo];
-        float bestd = cc.y + (-2.0f * (xc * cc.x));
-        int best = plo;
-        for (int c = plo + 1; c <= phi; c++) {
-            cc = tab->cand[c];
-            const float d = cc.y + (-2.0f * (xc * cc.x));
-            if (d < bestd || (d == bestd && tab->orig[c] < tab->orig[best])) { bestd = d; best = c; }
+    for (long long i0 = s; i0 < e; i0 += 64) {
+        const long long i = i0 + lane;
+        const bool have = i < e;
+        const float xc = have ? xs[i] - mean : 0.0f;
+        float bestd = INFINITY;
+        int best = plo, besto = 0x7fffffff;
+        for (int g0 = plo; g0 <= phi; g0 += 64) {
+            const int mine = g0 + lane;
+            const float2 cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
+            const int om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
+            const int cnt = min(64, phi - g0 + 1);
+            for (int c = 0; c < cnt; c++) {
+                const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.x), c));
+                const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.y), c));
+                const int oc = __builtin_amdgcn_readlane(om, c);
+                const float d = cy + (-2.0f * (xc * cx));
+                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = g0 + c; besto = oc; }
+            }
         }
-        if (best != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best; run_n = 0; run_s = 0; }
-        run_n++;
-        run_s += fix_f32(xc, Sft);
+        if (have) {
+            if (best != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best; run_n = 0; run_s = 0; }
+            run_n++;
+            run_s += fix_f32(xc, Sft);
+        }
     }
     if (run_n) km_shard_add(ws, run_p, run_s, run_n);
 }
@@ -1496,6 +1509,40 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
         const double T[3] = {Lj, Uj, Ujm1};
         if (top) { lo[0] = n; lo[1] = n; }   // a = b = n
         if (j == 0) hi[2] = 0;               // b_{-1} = 0
+        // First round from where the boundary was found last time (centres move little from one iteration to the next): probes
+        // at hint - 2^30 ... hint - 1, hint, hint + 1 ... hint + 2^30 and the last sample bracket the answer to within the
+        // distance it moved; the 64-ary rounds below finish inside that bracket.
+        {
+            const long long hint[3] = {ws->hint_a[j], ws->hint_b[j], j > 0 ? ws->hint_b[j - 1] : -1};
+            auto probe_at = [&](long long h, int t) -> long long {
+                long long p = t < 31 ? h - ((long long)1 << (30 - t)) : (t == 31 ? h : (t < 63 ? h + ((long long)1 << (t - 32)) : n - 1));
+                if (p < 0) p = 0;
+                if (p > n - 1) p = n - 1;
+                return p;
+            };
+            float v[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                v[k] = 0.0f;
+                if (lo[k] < hi[k] && hint[k] >= 0) v[k] = xs[probe_at(hint[k] < n ? hint[k] : n - 1, lane)];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (lo[k] < hi[k] && hint[k] >= 0) {
+                    const long long h = hint[k] < n ? hint[k] : n - 1;
+                    const double xc = (double)(v[k] - mean);
+                    const bool pred = (k == 0) ? (xc >= T[k]) : (xc > T[k]);
+                    const unsigned long long bal = __ballot(pred);
+                    if (bal == 0ull) lo[k] = n; // not even the last sample passes: the answer is n  (hi is n)
+                    else {
+                        const int f = __ffsll((long long)bal) - 1;
+                        hi[k] = probe_at(h, f);
+                        lo[k] = f == 0 ? 0 : probe_at(h, f - 1) + 1;
+                        if (lo[k] > hi[k]) lo[k] = hi[k]; // (clamped probes may coincide)
+                    }
+                }
+            }
+        }
         while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2])) {
             float v[3];
             long long step[3];
@@ -1531,6 +1578,7 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
             }
         }
         const long long a = uni_ll(lo[0]), b = uni_ll(lo[1]), bm = uni_ll(lo[2]);
+        if (lane == 0) { ws->hint_a[j] = a; ws->hint_b[j] = b; }
         KBSTAMP(16 * j + 8, a); KBSTAMP(16 * j + 9, b); KBSTAMP(16 * j + 10, bm);
         // ---- this centre's certain stretch [bm, a)
         if (a > bm) {
@@ -2263,7 +2311,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
         (&ws->shard_sum[0][0])[i] = 0; (&ws->shard_cnt[0][0])[i] = 0;
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
-    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; }
+    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
     if (tid == 0) { ws->q_n = 0; ws->q_pad = 0; }
 }
 
