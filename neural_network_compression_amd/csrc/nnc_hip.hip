@@ -807,6 +807,9 @@ struct KmWs {
     unsigned long long shard_cnt[KM_NSHARD][NNC_KMAX];
     // k_bounds: long stretches of samples whose cluster float32 cannot tell from the zones alone, cut into tiles any wave
     // may take (two self-validating words per record, see k_bounds); emptied by the kernel that consumes the sums
+    // what k_bounds needs of the CURRENT table, at an address that does not depend on which of the two tables is current
+    // (one round of loads less at the head of every iteration); k_finalize writes it next to tab[cur]
+    struct Bnd { int32_t ku, pad; double zr[NNC_KMAX], zl[NNC_KMAX]; float2 cand[NNC_KMAX]; uint16_t orig[NNC_KMAX]; } bnd;
     int32_t q_n, q_pad;
     long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
@@ -1335,12 +1338,12 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 // partition the vector.  A long undecided stretch (two centres closer than float32 can tell apart make their whole
 // neighbourhood undecided) is published as tiles that any wave of the launch may take.
 #ifdef NNC_DIAG
-#define KBSTAMP(slot, val) do { if (NNC_KM_TRACE_PTR && lane == 0) { NNC_KM_TRACE_PTR[(slot)] = (unsigned long long)(val); __threadfence_system(); } } while (0)
+#define KBSTAMP(slot, val) do { if (NNC_KM_TRACE_PTR && lane == 0) { NNC_KM_TRACE_PTR[(slot)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
 #else
 #define KBSTAMP(slot, val) do { } while (0)
 #endif
 #define KM_PB NNC_PREFIX_BLOCK
-#define KM_TILE 2048
+#define KM_TILE 1024
 #define KM_Q_VALID (1ull << 62)
 
 // a value every lane holds alike, moved to scalar registers (so that the control flow that depends on it is scalar)
@@ -1395,6 +1398,41 @@ __device__ __forceinline__ long long km_prefix_at(const float *__restrict__ xs, 
     return pblk[blk] + acc;
 }
 
+// the same in two halves, so that a caller can have the loads of several prefixes (and more) in flight before adding anything up
+struct KmPfx { float4 v; long long pb; int rem; };
+__device__ __forceinline__ KmPfx km_prefix_load(const float *__restrict__ xs, const long long *__restrict__ pblk, long long r, long long n, int lane)
+{
+    KmPfx p;
+    const long long blk = r >> 8, base = blk << 8;
+    p.rem = (int)(r - base);
+    p.pb = pblk[blk];
+    p.v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (p.rem > 0) {
+        const long long i0 = base + 4 * lane;
+        if (base + KM_PB <= n) p.v = *reinterpret_cast<const float4 *>(xs + i0);
+        else {
+            if (i0 + 0 < r) p.v.x = xs[i0 + 0];
+            if (i0 + 1 < r) p.v.y = xs[i0 + 1];
+            if (i0 + 2 < r) p.v.z = xs[i0 + 2];
+            if (i0 + 3 < r) p.v.w = xs[i0 + 3];
+        }
+    }
+    return p;
+}
+__device__ __forceinline__ long long km_prefix_finish(const KmPfx &p, float mean, int Sft, int lane)
+{
+    long long acc = 0;
+    if (p.rem > 0) { // wave-uniform
+        const int left = p.rem - 4 * lane; // how many of the four are below r
+        if (left > 0) acc += fix_f32(p.v.x - mean, Sft);
+        if (left > 1) acc += fix_f32(p.v.y - mean, Sft);
+        if (left > 2) acc += fix_f32(p.v.z - mean, Sft);
+        if (left > 3) acc += fix_f32(p.v.w - mean, Sft);
+        acc = wave_sum_ll(acc);
+    }
+    return p.pb + acc;
+}
+
 __device__ __forceinline__ void km_shard_add(KmWs *ws, int p, long long sum, unsigned long long cnt)
 {
     if (cnt) {
@@ -1422,7 +1460,6 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
         const bool tie1 = tab->orig[plo + 1] < tab->orig[plo];
         long long s0 = 0, s1 = 0;
         unsigned n0 = 0, n1 = 0;
-        KBSTAMP(16 * plo + 1, s);
         for (long long i0 = s; i0 < e; i0 += 256) { // four loads in flight per lane
             float v[4];
 #pragma unroll
@@ -1439,43 +1476,59 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
                 }
             }
         }
-        KBSTAMP(16 * plo + 2, e);
         s0 = wave_sum_ll(s0); s1 = wave_sum_ll(s1);
-        KBSTAMP(16 * plo + 3, s0);
         const long long m0 = wave_sum_ll((long long)n0), m1 = wave_sum_ll((long long)n1);
-        KBSTAMP(16 * plo + 4, m1);
         if (lane == 0) { km_shard_add(ws, plo, s0, (unsigned long long)m0); km_shard_add(ws, plo + 1, s1, (unsigned long long)m1); }
-        KBSTAMP(16 * plo + 5, 0xD0E);
         return;
     }
-    // three or more centres within rounding distance of each other: the general scan, one run of equal winners at a time.  The
-    // candidates sit in the lanes' registers (lane l holds centre plo + l of the current group of 64) and go round by readlane.
+    // three or more centres within rounding distance of each other: the general scan.  The candidates sit in the lanes'
+    // registers (lane l holds centre g0 + l of the current group of 64) and go round by readlane; a lane takes four samples
+    // per batch so that their loads are in flight together and every candidate is fetched once for the four.
     int run_p = -1;
     unsigned run_n = 0;
     long long run_s = 0;
-    for (long long i0 = s; i0 < e; i0 += 64) {
-        const long long i = i0 + lane;
-        const bool have = i < e;
-        const float xc = have ? xs[i] - mean : 0.0f;
-        float bestd = INFINITY;
-        int best = plo, besto = 0x7fffffff;
+    const int ncand = phi - plo + 1;
+    float2 cm0 = make_float2(0.0f, 0.0f);
+    int om0 = 0x7fffffff;
+    if (ncand <= 64 && lane < ncand) { cm0 = tab->cand[plo + lane]; om0 = (int)tab->orig[plo + lane]; }
+    for (long long i0 = s; i0 < e; i0 += 256) {
+        float xc[4], bestd[4];
+        int best[4], besto[4];
+        bool have[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long i = i0 + lane + 64 * u;
+            have[u] = i < e;
+            xc[u] = have[u] ? xs[i] - mean : 0.0f;
+            bestd[u] = INFINITY; best[u] = plo; besto[u] = 0x7fffffff;
+        }
         for (int g0 = plo; g0 <= phi; g0 += 64) {
-            const int mine = g0 + lane;
-            const float2 cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
-            const int om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
+            float2 cm = cm0;
+            int om = om0;
+            if (ncand > 64) {
+                const int mine = g0 + lane;
+                cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
+                om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
+            }
             const int cnt = min(64, phi - g0 + 1);
             for (int c = 0; c < cnt; c++) {
                 const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.x), c));
                 const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.y), c));
                 const int oc = __builtin_amdgcn_readlane(om, c);
-                const float d = cy + (-2.0f * (xc * cx));
-                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = g0 + c; besto = oc; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const float d = cy + (-2.0f * (xc[u] * cx));
+                    if (d < bestd[u] || (d == bestd[u] && oc < besto[u])) { bestd[u] = d; best[u] = g0 + c; besto[u] = oc; }
+                }
             }
         }
-        if (have) {
-            if (best != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best; run_n = 0; run_s = 0; }
-            run_n++;
-            run_s += fix_f32(xc, Sft);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (have[u]) {
+                if (best[u] != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best[u]; run_n = 0; run_s = 0; }
+                run_n++;
+                run_s += fix_f32(xc[u], Sft);
+            }
         }
     }
     if (run_n) km_shard_add(ws, run_p, run_s, run_n);
@@ -1489,20 +1542,56 @@ __device__ __forceinline__ int km_claim(int *counter, int lane)
 }
 
 // wave j's share of one rank-boundary pass (see above): centre j's certain stretch and the undecided stretch above it
+// sources of one pass: the zones and centres of the table the pass runs against (the fixed-address copy of the current table,
+// or -- counting pass against the previous centres -- that table itself)
+struct KmBndSrc { const double *zr, *zl; const float2 *cand; const uint16_t *orig; const int *ku; };
+#define KM_BND_R ((NNC_KMAX + 63) / 64)
+
 __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
-                                               const KmTab *__restrict__ tab, const int ku, const float mean, const int Sft,
+                                               const KmTab *__restrict__ tab, const KmBndSrc src, const int kmax, const float mean, const int Sft,
                                                const long long *__restrict__ pblk)
 {
+    // ---- one round of loads: every zone end (a lane holds those of the centres lane, lane + 64, ...; bounded by the caller's k,
+    // which is known before anything has arrived), the number of distinct centres, the two centres either side of this
+    // wave's boundary, where the boundaries were last time
+    const int R = (kmax + 63) >> 6;
+    double zrv[KM_BND_R], zlv[KM_BND_R];
+#pragma unroll
+    for (int r = 0; r < KM_BND_R; r++) {
+        zrv[r] = 0.0; zlv[r] = 0.0;
+        if (r < R) { const int q = lane + 64 * r; if (q < NNC_KMAX) { zrv[r] = src.zr[q]; zlv[r] = src.zl[q]; } }
+    }
+    const int jq = j < NNC_KMAX - 1 ? j : NNC_KMAX - 2;
+    const float2 cj0 = src.cand[jq], cj1r = src.cand[jq + 1];
+    const int oj0 = src.orig[jq], oj1r = src.orig[jq + 1];
+    const long long hint_a = ws->hint_a[jq], hint_b = ws->hint_b[jq], hint_bm = jq > 0 ? ws->hint_b[jq - 1] : -1;
+    const int ku = *src.ku;
     if (j < ku) {
         // ---- the zone ends that bound this wave's stretches
         double Uj = -INFINITY, Ujm1 = -INFINITY, Lj = INFINITY;
-        for (int q = lane; q < ku; q += 64) {
-            const double zr = tab->zr[q], zl = tab->zl[q];
-            if (q <= j) Uj = fmax(Uj, zr);
-            if (q < j) Ujm1 = fmax(Ujm1, zr);
-            if (q > j) Lj = fmin(Lj, zl);
+#pragma unroll
+        for (int r = 0; r < KM_BND_R; r++) {
+            const int q = lane + 64 * r;
+            if (r < R && q < ku) {
+                if (q <= j) Uj = fmax(Uj, zrv[r]);
+                if (q < j) Ujm1 = fmax(Ujm1, zrv[r]);
+                if (q > j) Lj = fmin(Lj, zlv[r]);
+            }
         }
+        const float2 cj1 = j + 1 < ku ? cj1r : cj0;
+        const bool tie1 = j + 1 < ku && oj1r < oj0;
         Uj = wave_max_d(Uj); Ujm1 = wave_max_d(Ujm1); Lj = wave_min_d(Lj);
+        // the highest centre that can still win somewhere below U_j: max{q : zl[q] <= U_j}  (j + 1 unless centres crowd)
+        int phi = j;
+#pragma unroll
+        for (int r = 0; r < KM_BND_R; r++) {
+            const int q = lane + 64 * r;
+            if (r < R && q < ku && q > j && zlv[r] <= Uj) phi = q;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) phi = max(phi, __shfl_xor(phi, off));
+        phi = uni_i(phi);
+        KBSTAMP(16 * j + 1, 0);
         const bool top = j == ku - 1; // no boundary above the last centre
         // ---- three searches in lock step.  State k: the answer lies in [lo, hi]; hi is n or a position known to satisfy the test
         long long lo[3] = {0, 0, 0}, hi[3] = {n, n, n};
@@ -1513,7 +1602,7 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
         // at hint - 2^30 ... hint - 1, hint, hint + 1 ... hint + 2^30 and the last sample bracket the answer to within the
         // distance it moved; the 64-ary rounds below finish inside that bracket.
         {
-            const long long hint[3] = {ws->hint_a[j], ws->hint_b[j], j > 0 ? ws->hint_b[j - 1] : -1};
+            const long long hint[3] = {hint_a, hint_b, hint_bm};
             auto probe_at = [&](long long h, int t) -> long long {
                 long long p = t < 31 ? h - ((long long)1 << (30 - t)) : (t == 31 ? h : (t < 63 ? h + ((long long)1 << (t - 32)) : n - 1));
                 if (p < 0) p = 0;
@@ -1543,6 +1632,7 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
                 }
             }
         }
+        KBSTAMP(16 * j + 2, 0);
         while ((lo[0] < hi[0]) | (lo[1] < hi[1]) | (lo[2] < hi[2])) {
             float v[3];
             long long step[3];
@@ -1579,21 +1669,42 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
         }
         const long long a = uni_ll(lo[0]), b = uni_ll(lo[1]), bm = uni_ll(lo[2]);
         if (lane == 0) { ws->hint_a[j] = a; ws->hint_b[j] = b; }
-        KBSTAMP(16 * j + 8, a); KBSTAMP(16 * j + 9, b); KBSTAMP(16 * j + 10, bm);
-        // ---- this centre's certain stretch [bm, a)
+        KBSTAMP(16 * j + 3, 0);
+        // ---- this centre's certain stretch [bm, a) and the undecided stretch above it, [max(a, bm), b): every load of both
+        // goes out before anything is added up (the block prefixes, the two partial blocks, up to four undecided samples a lane)
+        const long long s = a > bm ? a : bm;
+        const long long und = b - s;
+        if (NNC_KM_TRACE_PTR && lane == 0) NNC_KM_TRACE_PTR[16 * j + 8] = (unsigned long long)und;
+        const bool quick = und > 0 && und <= 256 && phi == j + 1; // few samples, two candidates: settled right here
+        float uv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (quick) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const long long i = s + lane + 64 * u; if (i < b) uv[u] = xs[i]; }
+        }
         if (a > bm) {
-            const long long sum = km_prefix_at(xs, pblk, a, n, mean, Sft, lane) - km_prefix_at(xs, pblk, bm, n, mean, Sft, lane);
+            const KmPfx pa = km_prefix_load(xs, pblk, a, n, lane), pm = km_prefix_load(xs, pblk, bm, n, lane);
+            const long long sum = km_prefix_finish(pa, mean, Sft, lane) - km_prefix_finish(pm, mean, Sft, lane);
             if (lane == 0) km_shard_add(ws, j, sum, (unsigned long long)(a - bm));
         }
-        // ---- the undecided stretch above it, [max(a, bm), b)
-        const long long s = a > bm ? a : bm;
-        if (b > s) {
-            int phi = j;
-            for (int q = lane; q < ku; q += 64) if (q > j && tab->zl[q] <= Uj) phi = q;
+        KBSTAMP(16 * j + 4, 0);
+        if (quick) {
+            long long s0 = 0, s1 = 0;
+            unsigned n0 = 0, n1 = 0;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) phi = max(phi, __shfl_xor(phi, off));
-            phi = uni_i(phi);
-            if (b - s > KM_TILE) { // long: as tiles, for everybody
+            for (int u = 0; u < 4; u++) {
+                if (s + lane + 64 * u < b) {
+                    const float xc = uv[u] - mean;
+                    const float d0 = cj0.y + (-2.0f * (xc * cj0.x));
+                    const float d1 = cj1.y + (-2.0f * (xc * cj1.x));
+                    const int q = fix_f32(xc, Sft);
+                    if (d1 < d0 || (d1 == d0 && tie1)) { s1 += q; n1++; } else { s0 += q; n0++; }
+                }
+            }
+            s0 = wave_sum_ll(s0); s1 = wave_sum_ll(s1);
+            const long long m0 = wave_sum_ll((long long)n0), m1 = wave_sum_ll((long long)n1);
+            if (lane == 0) { km_shard_add(ws, j, s0, (unsigned long long)m0); km_shard_add(ws, j + 1, s1, (unsigned long long)m1); }
+        } else if (und > 0) {
+            if (und > KM_TILE) { // long: as tiles, for everybody
                 int r = 0;
                 if (lane == 0) r = atomicAdd(&ws->q_n, 1);
                 r = uni_i(r);
@@ -1617,7 +1728,6 @@ __device__ __forceinline__ void km_bounds_help(const int j, const int lane, cons
     int nrec = 0;
     if (lane == 0) nrec = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     nrec = min(uni_i(nrec), (int)NNC_KMAX);
-    KBSTAMP(16 * j + 7, 2000 + nrec);
     for (int r = 0; r < nrec; r++) {
         unsigned long long w0 = 0, w1 = 0;
         if (lane == 0) {
@@ -1640,18 +1750,28 @@ __device__ __forceinline__ void km_bounds_help(const int j, const int lane, cons
 }
 
 __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
-                                               const long long *__restrict__ pblk)
+                                               const long long *__restrict__ pblk, int kmax)
 {
     const int lane = threadIdx.x & 63;
     const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (!(which & 2) && (ws->st.done | ws->st.paused)) return; // (which & 2: counting pass after the fit)
-    const KmTab *__restrict__ tab = &ws->tab[ws->cur ^ (which & 1)];
-    const int ku = tab->ku;
+    KBSTAMP(16 * j + 0, 0);
+    KmBndSrc src;
+    const KmTab *tab;
+    if (which & 1) { // counting pass against the previous centres: that table itself
+        tab = &ws->tab[ws->cur ^ 1];
+        src.zr = tab->zr; src.zl = tab->zl; src.cand = tab->cand; src.orig = tab->orig; src.ku = &tab->ku;
+    } else {
+        tab = &ws->tab[ws->cur]; // (needed only by long or crowded undecided stretches)
+        src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
+    }
+    const int stop = (which & 2) ? 0 : (ws->st.done | ws->st.paused); // (which & 2: counting pass after the fit)
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
-    km_bounds_wave(j, lane, xs, n, ws, tab, ku, mean, Sft, pblk);
+    if (stop) return;
+    km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk);
+    KBSTAMP(16 * j + 5, 0);
     km_bounds_help(j, lane, xs, ws, tab, mean, Sft);
-    KBSTAMP(16 * j + 11, 0xE0D);
+    KBSTAMP(16 * j + 6, 0);
 }
 
 // block sums of the fixed-point images of a sorted vector, then their exclusive scan (once per fit)
@@ -1983,8 +2103,10 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         cs[p] = v;
         tab->cand[p] = make_float2(v, v * v);
         tab->orig[p] = sou[p];
+        ws->bnd.cand[p] = make_float2(v, v * v);
+        ws->bnd.orig[p] = sou[p];
     }
-    if (tid == 0) { tab->ku = ku; ws->ku_cur = ku; ovf_n = 0; }
+    if (tid == 0) { tab->ku = ku; ws->ku_cur = ku; ws->bnd.ku = ku; ovf_n = 0; }
     FIN_SYNC();
     FSTAMP(4);
     // ---- zone of every centre: the x-interval [left, right] on which it can be the float32 arg-min,
@@ -2034,6 +2156,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                     }
                 }
                 tab->zl[p] = left; tab->zr[p] = right;
+                ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
                 gp = G - 1; hp_ = 0;
                 if (inv > 0.0) {
                     const double qa = (right - lo) / ra; // may be +-inf
@@ -2185,8 +2308,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         // round writes its stores through and drops this CU's cached copies)
         if (ws->st.done | ws->st.paused) break; // the same for every thread
         const KmTab *tab = &ws->tab[ws->cur];
-        const int ku = tab->ku;
-        for (int j = wv; j < ku; j += KM_THREADS / 64) km_bounds_wave(j, lane, xs, n, ws, tab, ku, mean, Sft, pblk);
+        const int ku = ws->bnd.ku;
+        KmBndSrc src;
+        src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
+        for (int j = wv; j < ku; j += KM_THREADS / 64) km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk);
         km_bounds_help(wv, lane, xs, ws, tab, mean, Sft);
         __threadfence();
         __syncthreads();
@@ -2273,7 +2398,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
 #define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket)
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
-    else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256);
+    else if (k > 0 && k <= 512) KM_LAUNCH_FIN(256, false, 256); // two centres per thread at most: four waves meet at the barriers instead of sixteen
     else KM_LAUNCH_FIN(KM_THREADS, false, KM_THREADS);
 #undef KM_LAUNCH_FIN
     LAUNCHCHK("k_finalize");
@@ -2440,7 +2565,7 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     if (p->prefix_dev && p->n > 0) {
         if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
         const int grid = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
-        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(grid), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev));
+        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(grid), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k);
         LAUNCHCHK("k_bounds");
         return NNC_OK;
     }
