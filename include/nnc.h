@@ -421,6 +421,9 @@ int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void
 #define NNC_PROF_FINALIZE 5          /* k_finalize (K-sized) */
 #define NNC_PROF_PREFIX 6            /* k_prefix_blocks */
 #define NNC_PROF_MINMAX 7            /* k_minmax */
+/* Which tags get events from now on (bit t = NNC_PROF_* tag t; default all): an event pair costs its launch a little, so a
+ * timed run may want the passes over the vector only. */
+int nnc_profile_tags(uint32_t mask);
 int nnc_profile_begin(int32_t max_launches);
 /* Waits for the recorded events; ms_out[i] / tags_out[i] = duration in ms and NNC_PROF_* tag of the i-th timed launch
  * (launch order), up to cap entries; count_out = launches timed.  Launches enqueued after the state machine had stopped

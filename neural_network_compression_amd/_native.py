@@ -125,6 +125,7 @@ SIGNATURES = {
     "nnc_merge_keys": (c_int, [c_void_p, c_i32, c_i32, c_void_p, c_i32, c_void_p]),
     "nnc_kmeans_reloc_scratch_bytes_sharded": (c_size, [c_i32, c_i32, c_i32]),
     "nnc_kmeans_relocate_windowed_sharded": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p]),
+    "nnc_profile_tags": (c_int, [ctypes.c_uint32]),
     "nnc_profile_begin": (c_int, [c_i32]),
     "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), ctypes.POINTER(c_i32), c_i64, ctypes.POINTER(c_i64)]),
     "nnc_huffman_lengths": (c_int, [ctypes.POINTER(c_i64), c_i32, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),

@@ -103,12 +103,15 @@ static std::mutex g_prof_mu;            // the pool is shared by every calling t
 static std::vector<ProfRec> g_prof_pool;
 static size_t g_prof_used = 0;
 static std::atomic<bool> g_prof_on{false};
+static std::atomic<uint32_t> g_prof_mask{0xFFFFFFFFu}; // which NNC_PROF_* tags get events (an event pair costs its launch a little)
 static int64_t g_prof_skipped = 0;
+
+extern "C" int nnc_profile_tags(uint32_t mask) { g_prof_mask = mask; return NNC_OK; }
 
 static void prof_take(int tag, hipEvent_t *a, hipEvent_t *b)
 {
     *a = nullptr; *b = nullptr;
-    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    if (!g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> tag) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_prof_mu);
     if (g_prof_on && g_prof_used < g_prof_pool.size()) { ProfRec &r = g_prof_pool[g_prof_used++]; r.tag = tag; *a = r.a; *b = r.b; }
     else g_prof_skipped++;
@@ -810,7 +813,7 @@ struct KmWs {
     // what k_bounds needs of the CURRENT table, at an address that does not depend on which of the two tables is current
     // (one round of loads less at the head of every iteration); k_finalize writes it next to tab[cur]
     struct Bnd { int32_t ku, pad; double zr[NNC_KMAX], zl[NNC_KMAX]; float2 cand[NNC_KMAX]; uint16_t orig[NNC_KMAX]; } bnd;
-    int32_t q_n, q_pad;
+    int32_t q_n, q_done; // records published; waves of the launch that have nothing left to publish
     long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
     int32_t q_next[NNC_KMAX];
@@ -1720,37 +1723,50 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
 }
 
 // tiles of long undecided stretches: every wave that comes through here helps
-__device__ __forceinline__ void km_bounds_help(const int j, const int lane, const float *__restrict__ xs, KmWs *__restrict__ ws,
-                                               const KmTab *__restrict__ tab, const float mean, const int Sft)
+// Tiles of long undecided stretches.  Every wave of the launch comes through here and takes tiles; with wait_for > 0 it stays
+// until that many waves have reported that they have nothing left to publish (q_done) and one more look at the queue after
+// that has found nothing to take -- so a stretch published late still finds the whole launch ready to share it.  A publisher
+// comes through here after its own record is out and leaves only when all its tiles are taken, so no tile depends on helpers.
+__device__ __forceinline__ void km_bounds_help(const int lane, const float *__restrict__ xs, KmWs *__restrict__ ws,
+                                               const KmTab *__restrict__ tab, const float mean, const int Sft, const int wait_for)
 {
-    // ---- tiles of long undecided stretches: every wave of the launch helps; the publisher itself comes through here after its
-    // own record is out, so every tile is taken by somebody who is still running
-    int nrec = 0;
-    if (lane == 0) nrec = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    nrec = min(uni_i(nrec), (int)NNC_KMAX);
-    for (int r = 0; r < nrec; r++) {
-        unsigned long long w0 = 0, w1 = 0;
+    for (;;) {
+        int fin = 1, nrec = 0;
         if (lane == 0) {
-            w0 = __hip_atomic_load(&ws->q_w0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            w1 = __hip_atomic_load(&ws->q_w1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wait_for > 0) fin = __hip_atomic_load(&ws->q_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= wait_for; // before the look at the queue
+            nrec = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        w0 = (unsigned long long)uni_ll((long long)w0); w1 = (unsigned long long)uni_ll((long long)w1);
-        if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
-        const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
-        const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
-        const int ntiles = (int)((e - s + KM_TILE - 1) / KM_TILE);
-        int t = km_claim(&ws->q_next[r], lane);
-        while (t < ntiles) {
-            const long long ts = s + (long long)t * KM_TILE;
-            const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
-            km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
-            t = km_claim(&ws->q_next[r], lane);
+        fin = uni_i(fin);
+        nrec = min(uni_i(nrec), (int)NNC_KMAX);
+        for (int r = 0; r < nrec; r++) {
+            unsigned long long w0 = 0, w1 = 0;
+            if (lane == 0) {
+                w0 = __hip_atomic_load(&ws->q_w0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1 = __hip_atomic_load(&ws->q_w1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            w0 = (unsigned long long)uni_ll((long long)w0); w1 = (unsigned long long)uni_ll((long long)w1);
+            if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
+            const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
+            const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
+            const int ntiles = (int)((e - s + KM_TILE - 1) / KM_TILE);
+            int taken = 0;
+            if (lane == 0) taken = __hip_atomic_load(&ws->q_next[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (uni_i(taken) >= ntiles) continue; // (spent: no need to bump its counter again)
+            int t = km_claim(&ws->q_next[r], lane);
+            while (t < ntiles) {
+                const long long ts = s + (long long)t * KM_TILE;
+                const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
+                km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
+                t = km_claim(&ws->q_next[r], lane);
+            }
         }
+        if (fin) break;
+        __builtin_amdgcn_s_sleep(40);
     }
 }
 
 __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
-                                               const long long *__restrict__ pblk, int kmax)
+                                               const long long *__restrict__ pblk, int kmax, int nbnd_wg)
 {
     const int lane = threadIdx.x & 63;
     const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1768,9 +1784,14 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
     if (stop) return;
-    km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk);
+    // workgroups beyond the boundary waves (nbnd_wg of them) only share long undecided stretches; everybody stays until every
+    // boundary wave has said that it has nothing more to publish
+    if ((int)blockIdx.x < nbnd_wg) {
+        km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk);
+        if (lane == 0) __hip_atomic_fetch_add(&ws->q_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
     KBSTAMP(16 * j + 5, 0);
-    km_bounds_help(j, lane, xs, ws, tab, mean, Sft);
+    km_bounds_help(lane, xs, ws, tab, mean, Sft, (int)gridDim.x > nbnd_wg ? 4 * nbnd_wg : 0);
     KBSTAMP(16 * j + 6, 0);
 }
 
@@ -1869,7 +1890,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         const int qn = min(ws->q_n, (int)NNC_KMAX);
         for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
-        if (tid == 0) ws->q_n = 0;
+        if (tid == 0) { ws->q_n = 0; ws->q_done = 0; }
     }
     // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
     // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
@@ -2312,7 +2333,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         KmBndSrc src;
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
         for (int j = wv; j < ku; j += KM_THREADS / 64) km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk);
-        km_bounds_help(wv, lane, xs, ws, tab, mean, Sft);
+        km_bounds_help(lane, xs, ws, tab, mean, Sft, 0);
         __threadfence();
         __syncthreads();
         if (tid < 64) km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc);
@@ -2437,7 +2458,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
-    if (tid == 0) { ws->q_n = 0; ws->q_pad = 0; }
+    if (tid == 0) { ws->q_n = 0; ws->q_done = 0; }
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -2564,8 +2585,11 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
 {
     if (p->prefix_dev && p->n > 0) {
         if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
-        const int grid = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
-        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(grid), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k);
+        const int nb = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
+        // plus workgroups that only share long undecided stretches (centres closer than float32 can tell apart make thousands of
+        // samples undecided at once): all resident together on the chip's CUs, so waiting on each other is safe
+        const int nh = (int)std::max<int64_t>(0, std::min<int64_t>(p->n / (64 * 1024), (int64_t)cu_count() - nb));
+        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(nb + nh), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k, nb);
         LAUNCHCHK("k_bounds");
         return NNC_OK;
     }
@@ -2676,7 +2700,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_counts_from_shards(KmWs *__restr
         const int qn = min(ws->q_n, (int)NNC_KMAX);
         for (int r = threadIdx.x; r < qn; r += KM_THREADS) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         __syncthreads();
-        if (threadIdx.x == 0) ws->q_n = 0;
+        if (threadIdx.x == 0) { ws->q_n = 0; ws->q_done = 0; }
     }
     for (int j = threadIdx.x; j < k; j += KM_THREADS) counts[j] = 0; // duplicates of a centre own nothing
     __syncthreads();

@@ -72,3 +72,15 @@ LENET_5 = [
     ("dense1", (2450, 256), (256,)),
     ("out", (256, 10), (10,)),
 ]
+
+
+def gpt2_small_layers():
+    """(name, shape) of the 122 tensors of BASELINE configs[4] (a GPT-2-small-sized model, 124.4 M weights): token and
+    position embeddings, then per block the four weight matrices, their biases and the two layer-norm gains."""
+    shapes = [("wte", (50257, 768)), ("wpe", (1024, 768))]
+    for l in range(12):
+        shapes += [(f"h{l}.attn.c_attn", (768, 2304)), (f"h{l}.attn.c_proj", (768, 768)),
+                   (f"h{l}.mlp.c_fc", (768, 3072)), (f"h{l}.mlp.c_proj", (3072, 768)),
+                   (f"h{l}.b_attn", (2304,)), (f"h{l}.b_proj", (768,)), (f"h{l}.b_fc", (3072,)), (f"h{l}.b_proj2", (768,)),
+                   (f"h{l}.ln1", (768,)), (f"h{l}.ln2", (768,))]
+    return shapes
