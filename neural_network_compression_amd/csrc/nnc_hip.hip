@@ -814,6 +814,7 @@ struct KmWs {
     // (one round of loads less at the head of every iteration); k_finalize writes it next to tab[cur]
     struct Bnd { int32_t ku, pad; double zr[NNC_KMAX], zl[NNC_KMAX]; float2 cand[NNC_KMAX]; uint16_t orig[NNC_KMAX]; } bnd;
     int32_t q_n, q_done; // records published; waves of the launch that have nothing left to publish
+    int32_t help_hint, help_pad; // the previous pass published long stretches: this one had better look at the queue (k_finalize sets it)
     long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
     int32_t q_next[NNC_KMAX];
@@ -1486,14 +1487,23 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
     }
     // three or more centres within rounding distance of each other: the general scan.  The candidates sit in the lanes'
     // registers (lane l holds centre g0 + l of the current group of 64) and go round by readlane; a lane takes four samples
-    // per batch so that their loads are in flight together and every candidate is fetched once for the four.
+    // per batch so that their loads are in flight together and every candidate is fetched once for the four.  Where float32
+    // cannot tell two centres apart the winner changes from one sample to the next, so the sums are gathered per candidate in
+    // LDS (one slot per candidate and wave) and go to the global sums once per call: thousands of samples of one stretch
+    // would otherwise queue up on the same few addresses.
+    __shared__ unsigned long long acc_sum[KM_THREADS / 64][64];
+    __shared__ unsigned acc_cnt[KM_THREADS / 64][64];
+    const int wv = (int)(threadIdx.x >> 6);
+    const int ncand = phi - plo + 1;
+    const bool use_lds = ncand <= 64;
+    if (use_lds) { acc_sum[wv][lane] = 0ull; acc_cnt[wv][lane] = 0u; }
     int run_p = -1;
     unsigned run_n = 0;
     long long run_s = 0;
-    const int ncand = phi - plo + 1;
     float2 cm0 = make_float2(0.0f, 0.0f);
     int om0 = 0x7fffffff;
-    if (ncand <= 64 && lane < ncand) { cm0 = tab->cand[plo + lane]; om0 = (int)tab->orig[plo + lane]; }
+    if (use_lds && lane < ncand) { cm0 = tab->cand[plo + lane]; om0 = (int)tab->orig[plo + lane]; }
+    wave_lds_fence();
     for (long long i0 = s; i0 < e; i0 += 256) {
         float xc[4], bestd[4];
         int best[4], besto[4];
@@ -1508,7 +1518,7 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
         for (int g0 = plo; g0 <= phi; g0 += 64) {
             float2 cm = cm0;
             int om = om0;
-            if (ncand > 64) {
+            if (!use_lds) {
                 const int mine = g0 + lane;
                 cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
                 om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
@@ -1528,13 +1538,21 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (have[u]) {
-                if (best[u] != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best[u]; run_n = 0; run_s = 0; }
-                run_n++;
-                run_s += fix_f32(xc[u], Sft);
+                if (use_lds) {
+                    atomicAdd(&acc_sum[wv][best[u] - plo], (unsigned long long)(long long)fix_f32(xc[u], Sft));
+                    atomicAdd(&acc_cnt[wv][best[u] - plo], 1u);
+                } else {
+                    if (best[u] != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best[u]; run_n = 0; run_s = 0; }
+                    run_n++;
+                    run_s += fix_f32(xc[u], Sft);
+                }
             }
         }
     }
-    if (run_n) km_shard_add(ws, run_p, run_s, run_n);
+    if (use_lds) {
+        wave_lds_fence();
+        if (lane < ncand) km_shard_add(ws, plo + lane, (long long)acc_sum[wv][lane], (unsigned long long)acc_cnt[wv][lane]);
+    } else if (run_n) km_shard_add(ws, run_p, run_s, run_n);
 }
 
 __device__ __forceinline__ int km_claim(int *counter, int lane)
@@ -1550,10 +1568,11 @@ __device__ __forceinline__ int km_claim(int *counter, int lane)
 struct KmBndSrc { const double *zr, *zl; const float2 *cand; const uint16_t *orig; const int *ku; };
 #define KM_BND_R ((NNC_KMAX + 63) / 64)
 
-__device__ __forceinline__ void km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
+__device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
                                                const KmTab *__restrict__ tab, const KmBndSrc src, const int kmax, const float mean, const int Sft,
-                                               const long long *__restrict__ pblk)
+                                               const long long *__restrict__ pblk, int *qn_seen)
 {
+    bool published = false;
     // ---- one round of loads: every zone end (a lane holds those of the centres lane, lane + 64, ...; bounded by the caller's k,
     // which is known before anything has arrived), the number of distinct centres, the two centres either side of this
     // wave's boundary, where the boundaries were last time
@@ -1677,8 +1696,21 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
         // goes out before anything is added up (the block prefixes, the two partial blocks, up to four undecided samples a lane)
         const long long s = a > bm ? a : bm;
         const long long und = b - s;
-        if (NNC_KM_TRACE_PTR && lane == 0) NNC_KM_TRACE_PTR[16 * j + 8] = (unsigned long long)und;
+        if (NNC_KM_TRACE_PTR && lane == 0) { NNC_KM_TRACE_PTR[16 * j + 8] = (unsigned long long)und; NNC_KM_TRACE_PTR[16 * j + 9] = (unsigned long long)(phi - j); NNC_KM_TRACE_PTR[16 * j + 10] = (unsigned long long)(a > bm ? a - bm : 0); }
         const bool quick = und > 0 && und <= 256 && phi == j + 1; // few samples, two candidates: settled right here
+        // a long stretch goes out as tiles for everybody, and at once: the others look at the queue a round of loads from now
+        if (und > KM_TILE) {
+            int r = 0;
+            if (lane == 0) r = atomicAdd(&ws->q_n, 1);
+            r = uni_i(r);
+            if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
+                published = true;
+                if (lane == 0) {
+                    __hip_atomic_store(&ws->q_w0[r], KM_Q_VALID | ((unsigned long long)j << 40) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&ws->q_w1[r], KM_Q_VALID | ((unsigned long long)phi << 40) | (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         float uv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (quick) {
 #pragma unroll
@@ -1689,6 +1721,8 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
             const long long sum = km_prefix_finish(pa, mean, Sft, lane) - km_prefix_finish(pm, mean, Sft, lane);
             if (lane == 0) km_shard_add(ws, j, sum, (unsigned long long)(a - bm));
         }
+        // (how many long stretches are out by now: asked here, looked at by the caller when this wave's own work is through)
+        if (lane == 0) *qn_seen = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         KBSTAMP(16 * j + 4, 0);
         if (quick) {
             long long s0 = 0, s1 = 0;
@@ -1706,20 +1740,9 @@ __device__ __forceinline__ void km_bounds_wave(const int j, const int lane, cons
             s0 = wave_sum_ll(s0); s1 = wave_sum_ll(s1);
             const long long m0 = wave_sum_ll((long long)n0), m1 = wave_sum_ll((long long)n1);
             if (lane == 0) { km_shard_add(ws, j, s0, (unsigned long long)m0); km_shard_add(ws, j + 1, s1, (unsigned long long)m1); }
-        } else if (und > 0) {
-            if (und > KM_TILE) { // long: as tiles, for everybody
-                int r = 0;
-                if (lane == 0) r = atomicAdd(&ws->q_n, 1);
-                r = uni_i(r);
-                if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
-                    if (lane == 0) {
-                        __hip_atomic_store(&ws->q_w0[r], KM_Q_VALID | ((unsigned long long)j << 40) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        __hip_atomic_store(&ws->q_w1[r], KM_Q_VALID | ((unsigned long long)phi << 40) | (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                } else km_bounds_range(xs, s, b, j, phi, tab, ws, mean, Sft, lane); // queue full (never reset by a consumer?): do it alone
-            } else km_bounds_range(xs, s, b, j, phi, tab, ws, mean, Sft, lane);
-        }
+        } else if (und > 0 && !published) km_bounds_range(xs, s, b, j, phi, tab, ws, mean, Sft, lane); // (also a long one the full queue refused)
     }
+    return published;
 }
 
 // tiles of long undecided stretches: every wave that comes through here helps
@@ -1733,7 +1756,8 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
     for (;;) {
         int fin = 1, nrec = 0;
         if (lane == 0) {
-            if (wait_for > 0) fin = __hip_atomic_load(&ws->q_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= wait_for; // before the look at the queue
+            if (wait_for > 0) fin = __hip_atomic_load(&ws->q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_for; // before the look at the queue
+            // (relaxed on purpose: a record missed here is still finished by its publisher; an acquire per poll would drop the caches of a thousand waves)
             nrec = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         fin = uni_i(fin);
@@ -1781,17 +1805,24 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
     }
     const int stop = (which & 2) ? 0 : (ws->st.done | ws->st.paused); // (which & 2: counting pass after the fit)
+    const int hint = ws->help_hint;
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
     if (stop) return;
     // workgroups beyond the boundary waves (nbnd_wg of them) only share long undecided stretches; everybody stays until every
     // boundary wave has said that it has nothing more to publish
+    bool published = false;
+    int qn_seen = 0; // lane 0's: the number of long stretches that were out when this wave's own loads went out
+    const bool waiting = (int)gridDim.x > nbnd_wg;
     if ((int)blockIdx.x < nbnd_wg) {
-        km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk);
-        if (lane == 0) __hip_atomic_fetch_add(&ws->q_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        published = km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk, &qn_seen);
+        if (waiting && lane == 0) __hip_atomic_fetch_add(&ws->q_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     KBSTAMP(16 * j + 5, 0);
-    km_bounds_help(lane, xs, ws, tab, mean, Sft, (int)gridDim.x > nbnd_wg ? 4 * nbnd_wg : 0);
+    // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
+    // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
+    // to see its own tiles through.
+    if (published || hint || waiting || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft, waiting ? 4 * nbnd_wg : 0);
     KBSTAMP(16 * j + 6, 0);
 }
 
@@ -1890,7 +1921,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         const int qn = min(ws->q_n, (int)NNC_KMAX);
         for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
-        if (tid == 0) { ws->q_n = 0; ws->q_done = 0; }
+        if (tid == 0) { ws->q_n = 0; ws->q_done = 0; ws->help_hint = qn > 0; }
     }
     // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
     // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
@@ -2332,8 +2363,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         const int ku = ws->bnd.ku;
         KmBndSrc src;
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
-        for (int j = wv; j < ku; j += KM_THREADS / 64) km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk);
-        km_bounds_help(lane, xs, ws, tab, mean, Sft, 0);
+        bool published = false;
+        int qn_seen = 0;
+        for (int j = wv; j < ku; j += KM_THREADS / 64) published |= km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk, &qn_seen);
+        if (published || ws->help_hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft, 0);
         __threadfence();
         __syncthreads();
         if (tid < 64) km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc);
@@ -2458,7 +2491,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
-    if (tid == 0) { ws->q_n = 0; ws->q_done = 0; }
+    if (tid == 0) { ws->q_n = 0; ws->q_done = 0; ws->help_hint = 0; ws->help_pad = 0; }
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -2588,7 +2621,8 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
         const int nb = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
         // plus workgroups that only share long undecided stretches (centres closer than float32 can tell apart make thousands of
         // samples undecided at once): all resident together on the chip's CUs, so waiting on each other is safe
-        const int nh = (int)std::max<int64_t>(0, std::min<int64_t>(p->n / (64 * 1024), (int64_t)cu_count() - nb));
+        int nh = (int)std::max<int64_t>(0, std::min<int64_t>(p->n / (64 * 1024), (int64_t)cu_count() - nb));
+        nh = 0; // (measured: a thousand waves waiting on the counter cost every launch 10 us and the long launches are not short of hands)
         NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(nb + nh), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k, nb);
         LAUNCHCHK("k_bounds");
         return NNC_OK;

@@ -30,7 +30,7 @@ def test_gpt2_small_layer_list_full_pipeline():
             host[name] = w
         tensors.append((name, torch.from_numpy(w).cuda()))
     total = sum(t.numel() for _, t in tensors)
-    assert total == 124_439_808
+    assert total == 124_419_840
 
     def run():
         out = {}

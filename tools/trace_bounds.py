@@ -29,12 +29,15 @@ while True:
         t0 = t[act, 0].min()
         rel = (t[act][:, :7] - t0) * 0.01
         und = t[act][:, 8]
+        ncand = t[act][:, 9] + 1
+        sure = t[act][:, 10]
         print(f"iteration {it}: {act.sum()} waves; start {np.median(rel[:,0]):.2f} us (max {rel[:,0].max():.2f}); median per phase (us since kernel start): "
               f"zones {np.median(rel[:,1]):.2f}, hint {np.median(rel[:,2]):.2f}, searches {np.median(rel[:,3]):.2f}, certain {np.median(rel[:,4]):.2f}, "
               f"undecided {np.median(rel[:,5]):.2f}, end {np.median(rel[:,6]):.2f}; last wave ends {rel[:,6].max():.2f}; undecided samples median {np.median(und):.0f} max {und.max()}")
         worst = np.argsort(rel[:, 6])[-3:]
         for w in worst:
-            print("   slow wave", int(np.nonzero(act)[0][w]), [round(float(v), 2) for v in rel[w]], "undecided", int(und[w]))
+            print("   slow wave", int(np.nonzero(act)[0][w]), [round(float(v), 2) for v in rel[w]], "undecided", int(und[w]), "candidates", int(ncand[w]), "certain", int(sure[w]))
+        print("   undecided total", int(und[:-4].sum()), "; waves with > 2 candidates:", int((ncand[:-4] > 2).sum()), "max candidates", int(ncand[:-4].max()))
         trace.zero_()
     if s.paused:
         km._relocate_and_resume(s)
