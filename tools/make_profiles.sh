@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 out=$PWD/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-python bench.py --steps 5 --warmup 1 > $out/bench_plain.json 2> $out/bench_plain.err
+python bench.py --steps 10 --warmup 2 > $out/bench_plain.json 2> $out/bench_plain.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $CMD > $out/bench_under_trace.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $CMD > /dev/null 2>&1
@@ -39,14 +39,19 @@ for name, v in write.items():
     if name[:60] in summ:
         summ[name[:60]]["WRITE_SIZE_KB_mean"] = sum(v) / len(v)
 json.dump(summ, open(os.path.join(out, "pmc_hbm_summary.json"), "w"), indent=1)
-acc = [k for k in summ if "k_assign<0" in k]
-traffic = None
-if acc:
-    s = summ[acc[0]]
+def hbm(prefix):
+    ks = [k for k in summ if prefix in k]
+    if not ks:
+        return None
+    s = summ[ks[0]]
     # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM)
-    traffic = 2.0 * s["FETCH_SIZE_KB_mean"] * 1024 + s.get("WRITE_SIZE_KB_mean", 0.0) * 1024
-json.dump({"k_assign_accumulate_hbm_bytes_per_launch": traffic,
-           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 3 --warmup 1`; "
+    return 2.0 * s["FETCH_SIZE_KB_mean"] * 1024 + s.get("WRITE_SIZE_KB_mean", 0.0) * 1024
+traffic = hbm("k_assign<1")
+json.dump({"k_assign_labels_hbm_bytes_per_launch": traffic,
+           "k_assign_accumulate_hbm_bytes_per_launch": hbm("k_assign<0"),
+           "k_bounds_hbm_bytes_per_launch": hbm("k_bounds"),
+           "k_threshold_hbm_bytes_per_launch": hbm("k_threshold"),
+           "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`; "
                   "bytes = 2 * FETCH_SIZE_KB * 1024 (gfx950 half-count correction for 16 B/lane streaming reads) + WRITE_SIZE_KB * 1024; mean over the live launches"},
           open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(summ, indent=1)[:1500])
