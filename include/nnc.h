@@ -201,7 +201,7 @@ size_t nnc_kmeans_workspace_bytes(int32_t k);
  * a 64-ary search (one wave per boundary), the sums of the stretches that are certain come from block prefix sums of the
  * fixed-point images (differences of exact integers: the same sums as adding the members one by one), and only the samples
  * inside a zone are evaluated with the exact float32 expression.  Same labels, same sums, O(K log N) instead of O(N) reads.
- * prefix_dev: nnc_kmeans_prefix_bytes(n) bytes; build once per fit, after nnc_kmeans_init's x_mean / fix_shift are known.
+ * prefix_dev: nnc_kmeans_prefix_bytes(n) bytes (per-block prefixes inside groups of 1024 blocks, then the group prefixes); build once per fit, after nnc_kmeans_init's x_mean / fix_shift are known.
  * x_sorted must be 16-byte aligned. */
 #define NNC_PREFIX_BLOCK 256
 size_t nnc_kmeans_prefix_bytes(int64_t n);

@@ -1347,6 +1347,7 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
 #define KBSTAMP(slot, val) do { } while (0)
 #endif
 #define KM_PB NNC_PREFIX_BLOCK
+#define KM_PG 1024 // blocks per group of the two-level prefix
 #define KM_TILE 1024
 #define KM_Q_VALID (1ull << 62)
 
@@ -1378,6 +1379,10 @@ __device__ __forceinline__ double wave_min_d(double v)
     return v;
 }
 
+// the group prefixes live behind the block prefixes in the caller's buffer
+__host__ __device__ __forceinline__ long long km_prefix_nblk(long long n) { return (n + NNC_PREFIX_BLOCK - 1) / NNC_PREFIX_BLOCK; }
+__device__ __forceinline__ const long long *km_pgrp(const long long *pblk, long long n) { return pblk + km_prefix_nblk(n) + 2; }
+
 // sum of fix(x~) over the first r samples: block prefix + the wave adds the rest of r's block
 __device__ __forceinline__ long long km_prefix_at(const float *__restrict__ xs, const long long *__restrict__ pblk, long long r,
                                                   long long n, float mean, int Sft, int lane)
@@ -1399,7 +1404,7 @@ __device__ __forceinline__ long long km_prefix_at(const float *__restrict__ xs, 
         }
         acc = wave_sum_ll(acc);
     }
-    return pblk[blk] + acc;
+    return pblk[blk] + km_pgrp(pblk, n)[blk / KM_PG] + acc;
 }
 
 // the same in two halves, so that a caller can have the loads of several prefixes (and more) in flight before adding anything up
@@ -1409,7 +1414,7 @@ __device__ __forceinline__ KmPfx km_prefix_load(const float *__restrict__ xs, co
     KmPfx p;
     const long long blk = r >> 8, base = blk << 8;
     p.rem = (int)(r - base);
-    p.pb = pblk[blk];
+    p.pb = pblk[blk] + km_pgrp(pblk, n)[blk / KM_PG];
     p.v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (p.rem > 0) {
         const long long i0 = base + 4 * lane;
@@ -1842,42 +1847,52 @@ __global__ __launch_bounds__(256) void k_prefix_blocks(const float *__restrict__
             for (int u = 0; u < 4; u++) if (i0 + u < n) acc += fix_f32(xs[i0 + u] - mean, Sft);
         }
         acc = wave_sum_ll(acc);
-        if (lane == 0) pblk[b + 1] = acc; // shifted by one: the scan turns it into "sum of all blocks before b + 1"
+        if (lane == 0) pblk[b] = acc;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) pblk[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) pblk[nblk] = 0; // one virtual block behind the last: its prefix is the total
 }
 
-// in-place inclusive scan of pblk[1 .. nblk] (so that pblk[b] = sum of the blocks before b), one workgroup
-__global__ __launch_bounds__(KM_THREADS) void k_prefix_scan(long long *__restrict__ pblk, long long nblk)
+// Two-level exclusive scan of the block sums: groups of KM_PG blocks, one workgroup per group (pblk[b] becomes the sum of the
+// blocks of b's group before b, gtot[g] the group's total), then one workgroup turns the group totals into their exclusive
+// prefixes pgrp[g].  The prefix at block b is pblk[b] + pgrp[b / KM_PG].
+__global__ __launch_bounds__(KM_THREADS) void k_prefix_groups(long long *__restrict__ pblk, long long nblk, long long *__restrict__ pgrp)
+{
+    __shared__ long long wave_tot[KM_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long b = (long long)blockIdx.x * KM_PG + tid;
+    const long long v = (b <= nblk) ? pblk[b] : 0; // (the sum of block b, as k_prefix_blocks left it; entry nblk: 0)
+    long long s = v;
+    for (int off = 1; off < 64; off <<= 1) { const long long t = __shfl_up(s, off); if (lane >= off) s += t; }
+    if (lane == 63) wave_tot[wv] = s;
+    __syncthreads();
+    long long pre = 0, tot = 0;
+    for (int w = 0; w < KM_THREADS / 64; w++) { if (w < wv) pre += wave_tot[w]; tot += wave_tot[w]; }
+    if (b <= nblk) pblk[b] = pre + s - v; // exclusive, in place: a thread reads and writes its own entry only
+    if (tid == 0) pgrp[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(KM_THREADS) void k_prefix_top(long long *__restrict__ pgrp, long long ngroups)
 {
     __shared__ long long wave_tot[KM_THREADS / 64];
     __shared__ long long carry_s;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    // tiles of KM_THREADS * 8 entries; a thread takes 8 consecutive ones
-    for (long long base = 1; base <= nblk; base += (long long)KM_THREADS * 8) {
-        long long v[8];
-        const long long i0 = base + (long long)tid * 8;
-#pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = (i0 + u <= nblk) ? pblk[i0 + u] : 0;
-#pragma unroll
-        for (int u = 1; u < 8; u++) v[u] += v[u - 1];
-        long long s = v[7];
+    for (long long base = 0; base < ngroups; base += KM_THREADS) {
+        const long long g = base + tid;
+        const long long v = g < ngroups ? pgrp[g] : 0;
+        long long s = v;
         for (int off = 1; off < 64; off <<= 1) { const long long t = __shfl_up(s, off); if (lane >= off) s += t; }
         if (lane == 63) wave_tot[wv] = s;
         __syncthreads();
-        long long pre = carry_s;
-        for (int w = 0; w < wv; w++) pre += wave_tot[w];
-        long long tot = 0;
-        for (int w = 0; w < KM_THREADS / 64; w++) tot += wave_tot[w];
-        const long long before = pre + (s - v[7]); // everything before this thread's eight
-#pragma unroll
-        for (int u = 0; u < 8; u++) if (i0 + u <= nblk) pblk[i0 + u] = before + v[u];
+        long long pre = carry_s, tot = 0;
+        for (int w = 0; w < KM_THREADS / 64; w++) { if (w < wv) pre += wave_tot[w]; tot += wave_tot[w]; }
+        if (g < ngroups) pgrp[g] = pre + s - v;
         __syncthreads();
         if (tid == 0) carry_s += tot;
         __syncthreads();
     }
+    if (tid == 0) pgrp[ngroups] = carry_s;
 }
 
 // ---- finalize / prepare kernel (one workgroup) -------------------------------------------
@@ -1949,16 +1964,19 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     // count (prev_counts); the host runs the full label comparison (strict convergence) only then.
     // (loaded up front by original index, so that the loads overlap the shard loads)
     const bool track = (mode == FIN_FROM_SHARDS) || (mode == FIN_FROM_PARTIALS && !resume);
-    long long pc[2] = {0, 0};
-    if (track)
-        for (int j = tid, r = 0; j < k; j += NT, r++) pc[r] = ws->prev_counts[j];
+    constexpr int RR = (NNC_KMAX + NT - 1) / NT; // centres per thread (2 with 1024 threads, 5 with 256, 17 with one wave)
+    long long pc[RR];
+#pragma unroll
+    for (int r = 0; r < RR; r++) { pc[r] = 0; const int j = tid + r * NT; if (track && j < k) pc[r] = ws->prev_counts[j]; }
     // second (and last) round of loads: the previous centres and the order the E-step of this iteration used
-    float cold_r[2] = {0.0f, 0.0f};
-    int spa[2] = {0, 0}, spb[2] = {0, 0}; // k <= 1040 < 2 * NT
+    float cold_r[RR];
+    int spa[RR], spb[RR];
+#pragma unroll
+    for (int r = 0; r < RR; r++) { cold_r[r] = 0.0f; spa[r] = 0; spb[r] = 0; }
     if (mode != FIN_INIT) {
         const uint16_t *so_e = ws->tab[cur].perm;
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
+        for (int r = 0; r < RR; r++) {
             const int j = tid + r * NT;
             if (j < k) { cold_r[r] = ws->c[cur][j]; spa[r] = so_e[j]; spb[r] = (j + 1 < k) ? so_e[j + 1] : 0; }
         }
@@ -1990,10 +2008,14 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     FIN_SYNC();
     if (track) {
         int count_diff = 0;
-        for (int j = tid, r = 0; j < k; j += NT, r++) {
-            const long long c = cnt_o[j];
-            count_diff |= (pc[r] != c);
-            ws->prev_counts[j] = c;
+#pragma unroll
+        for (int r = 0; r < RR; r++) {
+            const int j = tid + r * NT;
+            if (j < k) {
+                const long long c = cnt_o[j];
+                count_diff |= (pc[r] != c);
+                ws->prev_counts[j] = c;
+            }
         }
         const int any_diff = FIN_OR(count_diff);
         if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
@@ -2033,11 +2055,15 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         }
         FSTAMP(2);
         // ---- _center_shift and the tolerance test
-        for (int j = tid, r = 0; j < k; j += NT, r++) {
-            float d = cnew[j] - cold_r[r];
-            float s2 = d * d;
-            float sft = (float)sqrt((double)s2);
-            sq[j] = sft * sft;
+#pragma unroll
+        for (int r = 0; r < RR; r++) {
+            const int j = tid + r * NT;
+            if (j < k) {
+                float d = cnew[j] - cold_r[r];
+                float s2 = d * d;
+                float sft = (float)sqrt((double)s2);
+                sq[j] = sft * sft;
+            }
         }
         FIN_SYNC();
         const float tot = block_pairwise_sum<ONEWAVE>([&](int i) { return sq[i]; }, k, &heap);
@@ -2065,22 +2091,25 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     int still_sorted = 0;
     if (mode != FIN_INIT) {
         int ok = 1;
-        for (int p = tid, r = 0; p < k; p += NT, r++) {
-            const int a = spa[r];
-            so[p] = (uint16_t)a;
-            cs[p] = cnew[a];
-            if (p + 1 < k) {
-                const int b = spb[r];
-                const float va = cnew[a], vb = cnew[b];
-                ok &= (va < vb) || (va == vb && a < b);
+#pragma unroll
+        for (int r = 0; r < RR; r++) {
+            const int p = tid + r * NT;
+            if (p < k) {
+                const int a = spa[r];
+                so[p] = (uint16_t)a;
+                cs[p] = cnew[a];
+                if (p + 1 < k) {
+                    const int b = spb[r];
+                    const float va = cnew[a], vb = cnew[b];
+                    ok &= (va < vb) || (va == vb && a < b);
+                }
             }
         }
         still_sorted = FIN_AND(ok);
         // nearly sorted (two neighbours changed places): a few odd-even transposition passes repair it
         for (int pass = 0; pass < 3 && !still_sorted; pass++) {
             for (int parity = 0; parity < 2; parity++) {
-                const int p = 2 * tid + parity;
-                if (p + 1 < k) {
+                for (int p = 2 * tid + parity; p + 1 < k; p += 2 * NT) {
                     const float va = cs[p], vb = cs[p + 1];
                     const uint16_t a = so[p], b = so[p + 1];
                     if (!((va < vb) || (va == vb && a < b))) { cs[p] = vb; cs[p + 1] = va; so[p] = b; so[p + 1] = a; }
@@ -2178,8 +2207,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         const int rounds = (ku + NT - 1) / NT;
         int *wave_i = reinterpret_cast<int *>(wave_a);
         int carry_g = -2;
-        int gp_r[2], hp_r[2]; // ku <= 1040 < 2 * NT
-        for (int rd = 0; rd < rounds; rd++) {
+        for (int rd = 0; rd < rounds; rd++) { // (the raw G_p / H_p go to gcell / hcell; the scans below run over them in place)
             const int p = rd * NT + tid;
             int gp = -2, hp_ = G + 1;
             if (p < ku) {
@@ -2222,8 +2250,9 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                     else { hp_ = (int)qb; if ((double)hp_ < qb) hp_++; }
                 }
             }
-            gp_r[rd] = gp; hp_r[rd] = hp_;
+            if (p < ku) { gcell[p] = gp; hcell[p] = hp_; }
         }
+        FIN_SYNC();
         FSTAMP(11);
         // prefix max of G_p and suffix min of H_p, side by side (one pair of barriers for both)
         int *wave_g = reinterpret_cast<int *>(wave_a);
@@ -2232,8 +2261,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         const int lane = tid & 63, myw = tid >> 6;
         for (int it = 0; it < rounds; it++) {
             const int rg = it, rh = rounds - 1 - it; // the prefix runs up the rounds, the suffix down
-            int a = rg ? gp_r[1] : gp_r[0];
-            int b = rh ? hp_r[1] : hp_r[0];
+            int a = (rg * NT + tid < ku) ? gcell[rg * NT + tid] : -2;
+            int b = (rh * NT + tid < ku) ? hcell[rh * NT + tid] : G + 1;
             for (int off = 1; off < 64; off <<= 1) {
                 const int oa = __shfl_up(a, off), ob = __shfl_down(b, off);
                 if (lane >= off) a = max(a, oa);
@@ -2452,7 +2481,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
 #define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket)
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
-    else if (k > 0 && k <= 512) KM_LAUNCH_FIN(256, false, 256); // two centres per thread at most: four waves meet at the barriers instead of sixteen
+    else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256); // (measured at K = 257: one wave 23.6 us, four waves 14.6 / 17.7 us median / mean, sixteen 14.4 / 15.9)
     else KM_LAUNCH_FIN(KM_THREADS, false, KM_THREADS);
 #undef KM_LAUNCH_FIN
     LAUNCHCHK("k_finalize");
@@ -2593,7 +2622,8 @@ static const int g_ablation = 0, g_deal = 1;
 extern "C" size_t nnc_kmeans_prefix_bytes(int64_t n)
 {
     if (n < 0) return 0;
-    return (size_t)((n + KM_PB - 1) / KM_PB + 2) * sizeof(long long);
+    const long long nblk = (n + KM_PB - 1) / KM_PB;
+    return (size_t)(nblk + 2 + (nblk + 1 + KM_PG - 1) / KM_PG + 2) * sizeof(long long);
 }
 
 extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_params *p, int64_t *prefix_dev, void *stream)
@@ -2607,8 +2637,14 @@ extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_p
     const int grid = (int)std::max<long long>(1, std::min<long long>((nblk + 3) / 4, (long long)cu_count() * 8));
     NNC_LAUNCH_PROF(NNC_PROF_PREFIX, k_prefix_blocks, dim3(grid), dim3(256), 0, S(stream), x_sorted, (long long)p->n, p->x_mean, p->fix_shift, pb);
     LAUNCHCHK("k_prefix_blocks");
-    hipLaunchKernelGGL(k_prefix_scan, dim3(1), dim3(KM_THREADS), 0, S(stream), pb, nblk);
-    LAUNCHCHK("k_prefix_scan");
+    const long long ngroups = (nblk + 1 + KM_PG - 1) / KM_PG; // (entries 0 .. nblk)
+    long long *pg = pb + nblk + 2;
+    if (ngroups > 0) {
+        hipLaunchKernelGGL(k_prefix_groups, dim3((unsigned)ngroups), dim3(KM_THREADS), 0, S(stream), pb, nblk, pg);
+        LAUNCHCHK("k_prefix_groups");
+    }
+    hipLaunchKernelGGL(k_prefix_top, dim3(1), dim3(KM_THREADS), 0, S(stream), pg, ngroups);
+    LAUNCHCHK("k_prefix_top");
     return NNC_OK;
 }
 
