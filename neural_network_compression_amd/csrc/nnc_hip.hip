@@ -2600,7 +2600,7 @@ __global__ void k_debug_clock(int iters, float *out)
 extern "C" int nnc_debug_set_trace(unsigned long long *buf_dev)
 {
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_km_trace), &buf_dev, sizeof(buf_dev)));
-    unsigned long long *fin = buf_dev ? buf_dev + 4 * 1024 : nullptr; // finalize stamps live behind the 1024 workgroup records
+    unsigned long long *fin = buf_dev ? buf_dev + 6 * 1024 : nullptr; // finalize stamps live behind the workgroup / wave records (buffer: 8192 entries)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_fin_trace), &fin, sizeof(fin)));
     return NNC_OK;
 }
@@ -3364,7 +3364,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     __shared__ double zl_s[NNC_KMAX];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned long long *strc = NNC_KM_TRACE_PTR; // diagnostics: phase stamps behind the workgroup records
-#define RSTAMP(i) do { if (strc && tid == 0) strc[3000 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define RSTAMP(i) do { if (strc && tid == 0) strc[7000 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     RSTAMP(0);
     const int n_cand = meta[0];
     // (the relocation's own inputs -- centres, list of empty clusters -- do not depend on the selection: fetched now)
@@ -3450,7 +3450,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         if (total_ge <= KM_SURV_SMALL) break;
     }
     RSTAMP(1);
-    if (strc && tid == 0) { strc[3010] = (unsigned long long)n_cand; strc[3011] = (unsigned long long)total_ge; }
+    if (strc && tid == 0) { strc[7010] = (unsigned long long)n_cand; strc[7011] = (unsigned long long)total_ge; }
     int bad = 0;
     if (total_ge > KM_SURV_MAX) bad |= 128; // a crowd of exactly equal distances at the cut
     if (tid == 0) { s_nsurv = 0; s_bad = 0; }

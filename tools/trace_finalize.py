@@ -16,7 +16,7 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
     cdfs = pipeline.weight_distribution(x, True) if mode == "density" else None
     space = pipeline.initial_centroids(x, bits, mode, cdfs)
     km = kmeans.DeviceKMeans(x, space)
-    tr = torch.zeros(4 * 1024 + 16, dtype=torch.int64, device=dev)
+    tr = torch.zeros(8192, dtype=torch.int64, device=dev)
     acc = []
     for it in range(1, 16):
         tr.zero_()
@@ -27,7 +27,7 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
         torch.cuda.synchronize()
         nat.check(L.nnc_debug_set_trace(0))
         if it >= 6 and not st.paused:
-            t = tr.cpu().numpy()[4 * 1024: 4 * 1024 + 13]
+            t = tr.cpu().numpy()[6 * 1024: 6 * 1024 + 13]
             acc.append((t - t[0]) * 0.01)
         if st.paused:
             km._relocate_and_resume(st)
