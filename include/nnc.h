@@ -237,6 +237,17 @@ int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t ticket, void
  * one workgroup that iterates until the fit stops, pauses or `iters` iterations are through: pass max_iter and look once. */
 int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params *p, int32_t iters, void *host_mapped,
                                uint64_t ticket, void *stream);
+/* The whole Lloyd loop of one fit on one GPU as one call (what the host would do between two launches: batches of
+ * iterations sized from the decay of the centre shift, look-ins, windowed relocation of empty clusters), returning when the
+ * fit has stopped (status_out->done) or needs the caller: status_out->paused == 2 (a windowed selection could not be proven:
+ * full-pass relocation) or == 1 (windows not applicable, strict-convergence check due, scratch too small).  The caller
+ * relocates, resumes (nnc_kmeans_finalize(ws, 1)) and calls again.  host_mapped: 2 * (sizeof(nnc_kmeans_status) + 8) bytes
+ * of host memory the device can write (see nnc_kmeans_status_publish); *ticket_io: a counter that never repeats for this
+ * buffer; sorted: x_iter is in ascending order (windowed relocation allowed); reloc_scratch_dev: as for
+ * nnc_kmeans_relocate_windowed (may be NULL); *n_windowed_out: relocation events settled inside.  The calling thread polls. */
+int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_params *p, int32_t max_batch, int32_t sorted,
+                   void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped, uint64_t *ticket_io,
+                   nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream);
 int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream);
 /* counts_dev[j] (int64, k entries) = number of weights of x whose nearest centre is j, for the
  * current centres (which = 0) or the previous ones (which = 1): the index histogram the Huffman

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <cmath>
 #include <cstdio>
@@ -3695,6 +3696,83 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
                        reinterpret_cast<long long *>(keys), 1, hist0);
     LAUNCHCHK("k_reloc_select");
     return km_launch_finalize(reinterpret_cast<KmWs *>(ws), p, FIN_FROM_PARTIALS, 1, stream);
+}
+
+// --------------------------------------------------------------------------------------
+// The Lloyd loop of one fit on one GPU as ONE call: batches of iterations, the look-ins (the status block arrives in pinned
+// host memory, the calling thread polls the ticket), batch sizing from the decay of the centre shift, and the windowed
+// relocation of empty clusters -- everything the host does between two launches, without leaving the library.  It comes
+// back when the fit has stopped (status.done) or needs something only the caller can do: the full-pass relocation
+// (status.paused == 2: the proof of a windowed selection failed; paused == 1: windows not applicable, the strict-convergence
+// check is due, or the scratch is too small).  The caller handles that and calls again.
+// --------------------------------------------------------------------------------------
+static int km_wait_ticket(volatile unsigned long long *word, unsigned long long ticket, hipStream_t stream)
+{
+    unsigned long long spins = 0;
+    bool synced = false;
+    auto t0 = std::chrono::steady_clock::now();
+    while (*word != ticket) {
+        if ((++spins & 0x3FFF) == 0) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (el > 0.02 && !synced) { // a non-coherent mapping, or a device error: make the write visible / surface the error
+                hipError_t e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) return fail(NNC_EHIP, std::string("nnc_kmeans_fit: ") + hipGetErrorString(e));
+                synced = true;
+            } else if (el > 60.0) return fail(NNC_EHIP, "nnc_kmeans_fit: the status never arrived");
+        }
+    }
+    return NNC_OK;
+}
+
+extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_params *pp, int32_t max_batch, int32_t sorted,
+                              void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped, uint64_t *ticket_io,
+                              nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_fit");
+    if (rc) return rc;
+    if (!host_mapped || !ticket_io || !status_out || (reinterpret_cast<uintptr_t>(host_mapped) & 7) != 0) return fail(NNC_EINVAL, "nnc_kmeans_fit: null / unaligned pointer");
+    const nnc_kmeans_params p = *pp;
+    if (p.n != p.n_total) return fail(NNC_EINVAL, "nnc_kmeans_fit: single GPU only (sharded fits: nnc_kmeans_iterate_sharded)");
+    if (max_batch < 1) max_batch = 1;
+    const bool one_launch = km_one_launch_fit(&p, x_iter);
+    const size_t slot = sizeof(nnc_kmeans_status) + 8;
+    unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped); // two slots, used alternately
+    int batch = one_launch ? p.max_iter : 1; // the first iteration is where duplicate initial centres surface as empty clusters
+    int nwin = 0;
+    double s_prev = -1.0, s_last = -1.0;
+    int i_prev = 0, i_last = 0;
+    for (;;) {
+        const uint64_t ticket = ++(*ticket_io);
+        unsigned char *sl = hb + (ticket & 1) * slot;
+        if ((rc = nnc_kmeans_iterate_publish(x_iter, ws, &p, batch, sl, ticket, stream))) return rc;
+        if ((rc = km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(sl + sizeof(nnc_kmeans_status)), ticket, S(stream)))) return rc;
+        const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
+        *status_out = st;
+        if (st.done) break;
+        if (st.paused) {
+            const bool strict_check = st.iter >= 1 && st.same_counts;
+            const int32_t window = (sorted && st.paused == 1 && !strict_check) ? nnc_kmeans_reloc_window(p.n, st.n_empty) : 0;
+            if (window == 0 || !reloc_scratch_dev || reloc_scratch_bytes < nnc_kmeans_reloc_scratch_bytes(p.k, window)) break; // the caller's turn
+            if ((rc = nnc_kmeans_relocate_windowed(x_iter, ws, &p, st.n_empty, reloc_scratch_dev, reloc_scratch_bytes, stream))) return rc;
+            nwin++;
+            batch = one_launch ? p.max_iter : 1;
+            s_prev = s_last = -1.0;
+            continue;
+        }
+        if (one_launch) continue;
+        // size the next batch so that it ends about where the shift crosses the tolerance (launches enqueued after convergence
+        // are no-ops, but they still cost a dispatch)
+        s_prev = s_last; i_prev = i_last;
+        s_last = (double)st.shift_tot; i_last = st.iter;
+        batch = std::min(max_batch, batch * 2);
+        if (s_prev > 0.0 && s_last > 0.0 && s_prev > s_last && p.tol > 0.0f) {
+            const double rate = std::log(s_prev / s_last) / std::max(1, i_last - i_prev);
+            const double left = s_last > (double)p.tol ? std::log(s_last / (double)p.tol) / rate : 0.0;
+            batch = (int)std::max(1.0, std::min((double)max_batch, std::floor(left * 0.9)));
+        }
+    }
+    if (n_windowed_out) *n_windowed_out = nwin;
+    return NNC_OK;
 }
 
 // Sharded vector: every rank selects (and proves) its own n_empty farthest samples from its shard's windows; the ranks

@@ -92,9 +92,17 @@ def _status_landing(nbytes: int) -> torch.Tensor:
     return buf
 
 
+def _ticket_counter() -> ctypes.c_uint64:
+    """This host thread's ticket counter (shared with the library's own look-ins, nnc_kmeans_fit: tickets never repeat)."""
+    if getattr(_TLS, "ticket_c", None) is None:
+        _TLS.ticket_c = ctypes.c_uint64(0)
+    return _TLS.ticket_c
+
+
 def _next_ticket() -> int:
-    _TLS.ticket = getattr(_TLS, "ticket", 0) + 1
-    return _TLS.ticket
+    c = _ticket_counter()
+    c.value += 1
+    return int(c.value)
 
 
 class LayerStats:
@@ -503,9 +511,25 @@ class DeviceKMeans:
         """Runs to convergence.  Returns (QuantizedModel, values tensor or None) where
         values = cluster_centers_[labels_] as a device float32 vector (utility.py:239)."""
         strict_labels = None
+        if self.group is None:
+            # one GPU: the loop itself -- batches, look-ins, windowed relocations -- runs inside the library (nnc_kmeans_fit); it
+            # comes back when the fit has stopped or an empty-cluster event needs the full-pass relocation
+            st = nat.KMeansStatus()
+            nwin = ctypes.c_int32(0)
+            while True:
+                scratch = self._reloc_scratch
+                nat.check(self.L.nnc_kmeans_fit(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), self.batch,
+                                                1 if (self.sorted_everywhere and self.reloc == "auto") else 0,
+                                                ops._ptr(scratch), 0 if scratch is None else scratch.numel(), self._status_pin.data_ptr(),
+                                                ctypes.byref(_ticket_counter()), ctypes.byref(st), ctypes.byref(nwin), self.stream))
+                self.n_relocations += nwin.value
+                self.n_reloc_windowed += nwin.value
+                if st.done:
+                    break
+                self._relocate_and_resume(st)
         batch = MAX_ITER if self.one_launch else 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
-        while True:
+        while self.group is not None:
             st = self.iterate_and_look(batch)
             if st.done:
                 break
