@@ -125,6 +125,9 @@ size_t nnc_layer_stats_workspace_bytes(int64_t n);
 int nnc_layer_stats_f32(const float *x, int64_t n, float *out6_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
                         void *stream);
 
+/* ranks_out_dev[i] = #{ j : x_sorted[j] < values_dev[i] } for an ascending x_sorted: the histogram of
+ * get_weight_distribution (utility.py:366-372) from the value-sorted copy, as differences of the ranks of the 32 steps. */
+int nnc_rank_sorted_f32(const float *x_sorted, int64_t n, const float *values_dev, int32_t m, int64_t *ranks_out_dev, void *stream);
 /* counts_dev[b] += #{ i : steps[b] <= x[i] < steps[b+1] }, b = 0..30 (caller zeroes counts_dev). */
 int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps32_dev, int64_t *counts_dev,
                    void *stream);

@@ -66,6 +66,7 @@ SIGNATURES = {
     "nnc_minmax_signs_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_layer_stats_workspace_bytes": (c_size, [c_i64]),
     "nnc_layer_stats_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_rank_sorted_f32": (c_int, [c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p]),
     "nnc_hist31_f32": (c_int, [c_void_p, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "nnc_sort_workspace_bytes": (c_size, [c_i64]),
     "nnc_sort_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_size, c_void_p]),

@@ -706,6 +706,28 @@ extern "C" int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const f
     return NNC_OK;
 }
 
+// ranks_out[i] = #{ j : xs[j] < values[i] } in an ascending vector (lower bound; the same float32 comparison the histogram
+// kernel makes): the 31 bin counts of get_weight_distribution (utility.py:366-372) are differences of 32 such ranks.
+__global__ __launch_bounds__(64) void k_rank_sorted(const float *__restrict__ xs, long long n, const float *__restrict__ values, int m,
+                                                    long long *__restrict__ ranks_out)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= m) return;
+    const float v = values[i];
+    long long lo = 0, hi = n;
+    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (xs[mid] < v) lo = mid + 1; else hi = mid; }
+    ranks_out[i] = lo;
+}
+
+extern "C" int nnc_rank_sorted_f32(const float *x_sorted, int64_t n, const float *values_dev, int32_t m, int64_t *ranks_out_dev, void *stream)
+{
+    if (n < 0 || m < 0 || (m > 0 && (!values_dev || !ranks_out_dev)) || (n > 0 && !x_sorted)) return fail(NNC_EINVAL, "nnc_rank_sorted_f32: bad argument");
+    if (m == 0) return NNC_OK;
+    hipLaunchKernelGGL(k_rank_sorted, dim3((m + 63) / 64), dim3(64), 0, S(stream), x_sorted, (long long)n, values_dev, (int)m, reinterpret_cast<long long *>(ranks_out_dev));
+    LAUNCHCHK("k_rank_sorted");
+    return NNC_OK;
+}
+
 template <typename LT>
 __global__ __launch_bounds__(256) void k_bincount(const LT *__restrict__ labels, int64_t n, int k,
                                                   unsigned long long *__restrict__ counts)
@@ -1965,7 +1987,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     // count (prev_counts); the host runs the full label comparison (strict convergence) only then.
     // (loaded up front by original index, so that the loads overlap the shard loads)
     const bool track = (mode == FIN_FROM_SHARDS) || (mode == FIN_FROM_PARTIALS && !resume);
-    constexpr int RR = (NNC_KMAX + NT - 1) / NT; // centres per thread (2 with 1024 threads, 5 with 256, 17 with one wave)
+    constexpr int RR = 2; // centres per thread: the launcher picks NT >= k / 2 (64 threads up to 64 centres, 256 up to 256, 1024 beyond)
     long long pc[RR];
 #pragma unroll
     for (int r = 0; r < RR; r++) { pc[r] = 0; const int j = tid + r * NT; if (track && j < k) pc[r] = ws->prev_counts[j]; }

@@ -73,11 +73,16 @@ def weight_distribution_sorted(x_sorted: torch.Tensor, stats, group=None):
     steps = np.linspace(np.float32(stats.min_nonzero), np.float32(stats.max_nonzero), num=32)  # float32 under NumPy 2
     steps32 = np.ascontiguousarray(steps, dtype=np.float32)
     steps_d = torch.from_numpy(steps32).to(x_sorted.device)
-    ranks = torch.searchsorted(x_sorted, steps_d, right=False).to(torch.int64)  # #{w < steps[b]} in this shard
-    t = torch.cat([ranks, torch.tensor([stats.n_zero], dtype=torch.int64, device=x_sorted.device)])
+    from . import _native as nat
+
+    t = torch.empty(33, dtype=torch.int64, device=x_sorted.device)   # 32 ranks: #{w < steps[b]} in this shard; then this shard's zeros
+    nat.check(nat.load().nnc_rank_sorted_f32(x_sorted.data_ptr(), x_sorted.numel(), steps_d.data_ptr(), 32, t.data_ptr(), ops._stream(x_sorted)))
     if group is not None:
+        t[32] = int(stats.n_zero)
         sharding.allreduce_sum_(t, group)
     host = t.cpu().numpy()
+    if group is None:
+        host[32] = int(stats.n_zero)
     counts = np.diff(host[:32])
     zero = np.float32(0.0)
     inside = np.nonzero((steps32[:-1] <= zero) & (zero < steps32[1:]))[0]
