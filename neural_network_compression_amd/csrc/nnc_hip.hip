@@ -2419,11 +2419,18 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         int qn_seen = 0;
         for (int j = wv; j < ku; j += KM_THREADS / 64) published |= km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk, &qn_seen);
         if (published || ws->help_hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft, 0);
-        __threadfence();
+        // The sums went out as device-scope atomics (performed in L2); the first wave must not read them from a line its CU
+        // still holds from the last round: drop the CU's cached copies (acquire), no write-back needed.
         __syncthreads();
-        if (tid < 64) km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc);
-        __threadfence();
+        if (tid < 64) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc);
+        }
+        // What the first wave stored is read by the other waves of this workgroup only: same CU, same L1 -- a workgroup-scope
+        // release / acquire (the stores have left the wave) is all it takes.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     if (host_st && tid == 0) {
         *host_st = ws->st;
