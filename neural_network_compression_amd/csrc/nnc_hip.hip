@@ -1924,13 +1924,21 @@ __global__ __launch_bounds__(KM_THREADS) void k_prefix_top(long long *__restrict
 #define FIN_FROM_PARTIALS 2 // multi GPU / resume: partials already hold the global sums
 #define FIN_PACK_ONLY 3     // reduce shards -> partials, nothing else
 
+// 1 / d, a little too large rather than too small (float32 reciprocal widened by 2^-20): a zone end that comes out a hair
+// further from its midpoint is still a valid zone, and the division is the slowest thing in the zone loop
+__device__ __forceinline__ double km_rcp_up(double d)
+{
+    const float r = __frcp_rn((float)d);
+    return (d > 1e-37 && d < 1e37) ? (double)r * (1.0 + 9.5367431640625e-07) : 1.0 / d;
+}
+
 // NT threads: a fit with few centres runs it as a single wave (64) or four (256), for which the many barriers and
 // wave-to-wave hand-overs of the scans cost next to nothing; NT >= k is all it needs (k > 1024 takes two rounds of 1024).
 // WAVE (NT == 64 only): the body is run by ONE wave of a larger workgroup, so it may not use workgroup barriers; the
 // wave's own lock step (plus a compiler fence) orders its LDS traffic.  Returns true if new zones were left
 // (gcell / hcell / ku_out = {ku, cur} filled), i.e. the cell table has to be rebuilt.
 template <int NT, bool ONEWAVE>
-__device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out)
+__device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out, const bool lazy = false)
 {
     static_assert(!ONEWAVE || NT == 64, "the barrier-free form is for a single wave");
 #define FIN_SYNC() do { if (ONEWAVE) wave_lds_fence(); else __syncthreads(); } while (0)
@@ -2244,7 +2252,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                     if (delta > 0.0) {
                         const double cm = fmax(fabs(cp), fabs(cq));
                         const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                        right = fmin(right, mid + E / delta);
+                        right = fmin(right, mid + E * km_rcp_up(delta));
                     }
                 }
                 for (int q = p - 1; q >= 0; q--) {
@@ -2255,13 +2263,13 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                     if (delta > 0.0) {
                         const double cm = fmax(fabs(cp), fabs(cq));
                         const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                        left = fmax(left, mid - E / delta);
+                        left = fmax(left, mid - E * km_rcp_up(delta));
                     }
                 }
                 tab->zl[p] = left; tab->zr[p] = right;
                 ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
                 gp = G - 1; hp_ = 0;
-                if (inv > 0.0) {
+                if (inv > 0.0 && !lazy) {
                     const double qa = (right - lo) / ra; // may be +-inf
                     // largest g with g <= qa; the relative slack covers the rounding of the quotient
                     gp = (qa >= (double)(G - 1)) ? (G - 1) : (qa < 0.0 ? -1 : (int)(qa * (1.0 + 1e-12)));
@@ -2277,6 +2285,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         }
         FIN_SYNC();
         FSTAMP(11);
+        if (!lazy) { // (the rank-boundary iterations do not use the cell side of the zones: k_cells works it out on demand)
         // prefix max of G_p and suffix min of H_p, side by side (one pair of barriers for both)
         int *wave_g = reinterpret_cast<int *>(wave_a);
         int *wave_h = reinterpret_cast<int *>(wave_b);
@@ -2310,12 +2319,13 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             carry_g = totg; carry_h = toth;
             FIN_SYNC();
         }
+        }
     }
     FSTAMP(5);
     FSTAMP(6);
     // ---- the cell table itself is built by k_cells (many workgroups: one CU is VALU-bound on it)
-    for (int p = tid; p < ku; p += NT) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
-    if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = ONEWAVE ? 0 : 1; ku_out[0] = ku; ku_out[1] = cur; }
+    if (!lazy) for (int p = tid; p < ku; p += NT) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
+    if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = (ONEWAVE || lazy) ? 0 : 1; ku_out[0] = ku; ku_out[1] = cur; }
     FSTAMP(7);
 #undef FSTAMP
 #undef FIN_SYNC
@@ -2358,7 +2368,7 @@ __device__ __forceinline__ uint16_t km_cell_entry(int g, int G, int ku, const in
 template <int NT, bool FUSED>
 __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume,
                                                                       nnc_kmeans_status *host_st, unsigned long long *host_ticket,
-                                                                      unsigned long long ticket)
+                                                                      unsigned long long ticket, int lazy)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
     __shared__ int fin_go, fin_kc[2], fin_novf; // fin_kc: {distinct centres, current table} from the body
@@ -2368,8 +2378,8 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
         if (tid == 0) { fin_go = 0; fin_novf = 0; }
         __syncthreads();
         if (tid < NT) {
-            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc);
-            if (tid == 0) __hip_atomic_store(&fin_go, built ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0);
+            if (tid == 0) __hip_atomic_store(&fin_go, (built && !lazy) ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         int go; // every path of the body ends in the store above, so the wait is bounded by the body's run time
         while ((go = __hip_atomic_load(&fin_go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0) __builtin_amdgcn_s_sleep(1);
@@ -2381,7 +2391,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
             if (tid == 0) tab->n_ovf = fin_novf;
         }
     } else {
-        km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc);
+        km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0);
     }
     if (host_st) {
         __syncthreads();
@@ -2424,7 +2434,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         __syncthreads();
         if (tid < 64) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc);
+            km_finalize_body<64, true>(ws, FIN_FROM_SHARDS, 0, gcell, hcell, fin_kc, true);
         }
         // What the first wave stored is read by the other waves of this workgroup only: same CU, same L1 -- a workgroup-scope
         // release / acquire (the stores have left the wave) is all it takes.
@@ -2464,8 +2474,46 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     if ((int)(blockIdx.x * KM_THREADS) >= G) return;
     KmTab *tab = &ws->tab[ws->cur ^ (which & 1)];
     const int ku = force ? tab->ku : ws->ku_cur;
-    for (int p = threadIdx.x; p < ku; p += KM_THREADS) { gcell[p] = tab->gc[p]; hcell[p] = tab->hc[p]; }
-    __syncthreads();
+    if (!force) {
+        for (int p = threadIdx.x; p < ku; p += KM_THREADS) { gcell[p] = tab->gc[p]; hcell[p] = tab->hc[p]; }
+        __syncthreads();
+    } else {
+        // on demand: the cell side of the zones (see km_finalize_body): centre p can open cells <= G_p and close cells >= H_p,
+        // rounded outwards, then made monotone (prefix max / suffix min); every workgroup works it out for itself
+        const double U = 5.9604644775390625e-08;
+        const double lo = (double)ws->p.lo, inv = (double)ws->inv;
+        const double ra = inv > 0.0 ? (1.0 - 4.0 * U) / inv * (1.0 - 4.0 * U) : 0.0;
+        const double rb = inv > 0.0 ? (1.0 + 4.0 * U) / inv * (1.0 + 4.0 * U) : 0.0;
+        for (int p = threadIdx.x; p < ku; p += KM_THREADS) {
+            const double left = tab->zl[p], right = tab->zr[p];
+            int gp = G - 1, hp_ = 0;
+            if (inv > 0.0) {
+                const double qa = (right - lo) / ra;
+                gp = (qa >= (double)(G - 1)) ? (G - 1) : (qa < 0.0 ? -1 : (int)(qa * (1.0 + 1e-12)));
+                if (gp > G - 1) gp = G - 1;
+                const double qb = ((left - lo) / rb - 1.0) * (1.0 - 1e-12);
+                if (qb <= 0.0) hp_ = 0;
+                else if (qb >= (double)G) hp_ = G;
+                else { hp_ = (int)qb; if ((double)hp_ < qb) hp_++; }
+            }
+            gcell[p] = gp; hcell[p] = hp_;
+        }
+        __syncthreads();
+        for (int off = 1; off < ku; off <<= 1) { // Hillis-Steele, two entries a thread (ku <= NNC_KMAX < 2 * KM_THREADS)
+            int a[2], b[2];
+            for (int r = 0; r < 2; r++) {
+                const int q = threadIdx.x + r * KM_THREADS;
+                a[r] = (q < ku) ? ((q >= off) ? max(gcell[q], gcell[q - off]) : gcell[q]) : 0;
+                b[r] = (q < ku) ? ((q + off < ku) ? min(hcell[q], hcell[q + off]) : hcell[q]) : 0;
+            }
+            __syncthreads();
+            for (int r = 0; r < 2; r++) {
+                const int q = threadIdx.x + r * KM_THREADS;
+                if (q < ku) { gcell[q] = a[r]; hcell[q] = b[r]; }
+            }
+            __syncthreads();
+        }
+    }
     if (g >= G) return;
     tab->cell[g] = km_cell_entry(g, G, ku, gcell, hcell, &tab->n_ovf, tab->ovf);
 }
@@ -2508,7 +2556,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
     nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
-#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket)
+#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, lazy ? 1 : 0)
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
     else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256); // (measured at K = 257: one wave 23.6 us, four waves 14.6 / 17.7 us median / mean, sixteen 14.4 / 15.9)
