@@ -350,6 +350,27 @@ int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code,
 int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * A whole fit of a short tensor in one launch, in the reference's own arithmetic: KMeans(n_clusters=k, init=space, n_init=1,
+ * algorithm="full").fit (common/utility.py:237-238) with the M-step as scikit-learn runs it on one thread -- float32 running
+ * sums in sample order (_k_means_lloyd.pyx:215-218), float32(1 / count) averaging (_k_means_common.pyx:274-296) -- so that
+ * centres, indices and n_iter_ are the reference's bit for bit (what stays open is what scikit-learn leaves to
+ * numpy.argpartition: pairing and ties at a relocation cut, reported as in nnc_kmeans_status).  One workgroup, everything
+ * on chip: NumPy-exact mean / variance, centring, E-step (brute force), M-step, relocation, stopping rules, final E-step,
+ * decode.  n <= NNC_REF_NMAX, k <= NNC_REF_KMAX.
+ *   x                : n float32 (un-centred, original order);  centers_init_dev: k float32 (un-centred)
+ *   tol              : scikit-learn's relative tolerance (1e-4)
+ *   labels_out[n] uint8, values_out[n] float32 (may be NULL) = cluster_centers_[labels_], centers_out[k] (un-centred),
+ *   counts_out[k] int64 (may be NULL) = index histogram
+ *   result_dev       : 32 bytes {int32 n_iter, stop (1 tol, 2 max_iter, 3 labels unchanged), n_relocations, reloc_ties,
+ *                      reloc_multi, pad; float x_mean, tol_abs}
+ * ---------------------------------------------------------------------------------- */
+#define NNC_REF_NMAX 4096
+#define NNC_REF_KMAX 128
+int nnc_kmeans_fit_reference_f32(const float *x, int32_t n, const float *centers_init_dev, int32_t k, int32_t max_iter, float tol,
+                                 uint8_t *labels_out, float *values_out, float *centers_out, int64_t *counts_out,
+                                 void *result_dev, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * k-means++ seeding: the reference's 4th initialisation mode, get_quantized_weight(mode="kmeans++") =
  * KMeans(n_clusters=2**bits).fit(...) (common/utility.py:228-232) -> scikit-learn's _kmeans_plusplus
  * (cluster/_kmeans.py:163-253) on the mean-centred float32 weights.  The host draws the random numbers from NumPy's

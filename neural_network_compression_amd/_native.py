@@ -105,6 +105,7 @@ SIGNATURES = {
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
+    "nnc_kmeans_fit_reference_f32": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "nnc_kmeanspp_trials": (c_i32, [c_i32]),
     "nnc_kmeanspp_workspace_bytes": (c_size, [c_i64, c_i32]),
     "nnc_kmeanspp_seed_f32": (c_int, [c_void_p, c_i64, c_f32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),

@@ -197,7 +197,7 @@ def kmeans_plusplus_init(x: torch.Tensor, k: int, stats=None):
     return x[ids].cpu().numpy(), ids.cpu().numpy()
 
 
-def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=None):
+def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=None, arith="auto"):
     """Replace every weight by the centroid of its k-means cluster (2**bits centroids;
     2**bits + 1 for ``density``).  Returns ``(quantized weights, fitted model)`` where the
     model exposes ``cluster_centers_``, ``labels_`` and ``n_iter_`` like the scikit-learn
@@ -209,7 +209,9 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=N
     k-means++ from NumPy's global generator (kmeans_plusplus_init), then runs the same Lloyd fit.
 
     ``group``: a torch.distributed process group when ``layer_weight`` is this rank's
-    contiguous shard of a longer vector (shards start on multiples of 8192 elements)."""
+    contiguous shard of a longer vector (shards start on multiples of 8192 elements).
+    ``arith``: "auto" fits tensors of up to 4096 weights in scikit-learn's own summation order (kmeans.fit_reference: the
+    reference's centres bit for bit) and longer ones with exact fixed-point sums; "fixed" forces the latter."""
     n = int(np.prod(layer_weight.shape))
     if group is None and n < (2 ** bits) + 1:
         print("not enough bits:", n, " vs ", 2 ** bits)
@@ -223,15 +225,13 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=N
         if group is not None:
             raise NotImplementedError("kmeans++ seeding needs the whole vector on one GPU")
         space, _ = kmeans_plusplus_init(x, 2 ** bits)
-        km = _kmeans.DeviceKMeans(x, space)
-        model, values = km.fit(want_values=True)
+        model, values = _kmeans.fit_vector(x, space, want_values=True, arith=arith)
         shape = tuple(layer_weight.shape)
         return (values.cpu().numpy().reshape(shape), model) if was_numpy else (values.view(shape), model)
     if group is not None and mode != "density":
         raise NotImplementedError("sharded fits take an explicit init: use kmeans.DeviceKMeans")
     space = _init_space(x, n, bits, mode, cdfs)
-    km = _kmeans.DeviceKMeans(x, np.asarray(space, dtype=np.float32), group=group)
-    model, values = km.fit(want_values=True)
+    model, values = _kmeans.fit_vector(x, np.asarray(space, dtype=np.float32), want_values=True, arith=arith, group=group)
     shape = tuple(layer_weight.shape)
     if was_numpy:
         return values.cpu().numpy().reshape(shape), model

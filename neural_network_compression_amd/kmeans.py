@@ -166,6 +166,65 @@ def sorted_copy(x: torch.Tensor, stats: LayerStats) -> torch.Tensor:
     return out
 
 
+REF_NMAX, REF_KMAX = 4096, 128   # include/nnc.h NNC_REF_NMAX / NNC_REF_KMAX
+
+
+def reference_fit_applies(n: int, k: int, group=None) -> bool:
+    """A short tensor on one GPU: the whole fit runs as one launch in the reference's own arithmetic (fit_reference)."""
+    return group is None and k <= n <= REF_NMAX and k <= REF_KMAX
+
+
+def fit_reference(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = TOL, want_values: bool = True):
+    """KMeans(n_clusters=k, init=init[:, None], n_init=1, algorithm="full").fit(x[:, None]) (utility.py:237-238) for a short
+    vector, in ONE launch and in scikit-learn's own arithmetic (include/nnc.h, nnc_kmeans_fit_reference_f32): float32
+    running sums in sample order, so centres, indices and n_iter_ are the reference's bit for bit.
+    Returns (QuantizedModel, values or None) like DeviceKMeans.fit."""
+    x = x.reshape(-1)
+    ops._require_cuda(x, "x", torch.float32)
+    L = nat.load()
+    init = np.ascontiguousarray(np.asarray(init, dtype=np.float32).reshape(-1))
+    n, k = x.numel(), int(init.size)
+    if not reference_fit_applies(n, k):
+        raise ValueError(f"fit_reference: n={n}, k={k} outside k <= n <= {REF_NMAX}, k <= {REF_KMAX}")
+    dev, stream = x.device, ops._stream(x)
+    init_d = torch.from_numpy(init).to(dev)
+    lab = torch.empty(n, dtype=torch.uint8, device=dev)
+    vals = torch.empty(n, dtype=torch.float32, device=dev) if want_values else None
+    # one device block for everything the host reads back: centres (k float32), result (8 x 4 bytes; the diagnostic build
+    # appends 8 int64 phase times)
+    kp = (k + 1) & ~1
+    back = torch.empty(kp + 8 + 16, dtype=torch.float32, device=dev)
+    counts = torch.empty(k, dtype=torch.int64, device=dev)
+    nat.check(L.nnc_kmeans_fit_reference_f32(x.data_ptr(), n, init_d.data_ptr(), k, int(max_iter), float(tol), lab.data_ptr(), ops._ptr(vals),
+                                             back.data_ptr(), counts.data_ptr(), back.data_ptr() + 4 * kp, stream))
+    host = back.cpu().numpy()
+    res = host[kp: kp + 8].view(np.int32)
+    model = QuantizedModel(host[:k].copy(), lab, int(res[0]), int(res[2]), {1: "tol", 2: "max_iter", 3: "strict"}.get(int(res[1]), "?"))
+    model.counts_device_ = counts
+    model.n_reloc_windowed_ = 0
+    model.reloc_tie_ = int(res[3])
+    model.n_reloc_multi_ = int(res[4])
+    model.arith_ = "reference"
+    model.phase_times_ = host[kp + 8:].view(np.int64)   # (diagnostic build only)
+    return model, vals
+
+
+def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "auto", group=None, **kw):
+    """The fit behind get_quantized_weight / compress_layer.  ``arith``: "reference" = scikit-learn's float32 running sums
+    (short tensors on one GPU only), "fixed" = exact fixed-point sums (any size, any number of GPUs), "auto" = reference
+    where it applies."""
+    if arith not in ("auto", "reference", "fixed"):
+        raise ValueError("arith must be 'auto', 'reference' or 'fixed'")
+    k = int(np.asarray(init).size)
+    if arith == "reference" or (arith == "auto" and reference_fit_applies(x.numel(), k, group)):
+        if group is not None:
+            raise ValueError("arith='reference' is a single-GPU fit")
+        return fit_reference(x, init, want_values=want_values)
+    model, vals = DeviceKMeans(x, init, group=group, **kw).fit(want_values=want_values)
+    model.arith_ = "fixed"
+    return model, vals
+
+
 class DeviceKMeans:
     """One fit = one instance.  ``x`` float32, 1-D, contiguous, CUDA."""
 

@@ -7,6 +7,8 @@ Huffman length histogram the north star adds (the reference stops at the index g
 """
 from __future__ import annotations
 
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 
 import numpy as np
@@ -124,10 +126,10 @@ def initial_centroids(x: torch.Tensor, bits: int, mode: str, cdfs=None, group=No
 
 def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int = 4, mode: str = "linear",
                    with_cdf: bool | None = None, group=None, huffman: bool = True,
-                   want_values: bool = True, comm=None) -> LayerResult:
+                   want_values: bool = True, comm=None, arith: str = "auto") -> LayerResult:
     """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part.
     ``group``: torch.distributed group of one rank per GPU when `x` is a shard; ``comm`` (sharding.RcclComm over the same
-    ranks) moves the per-iteration exchange of the fit into the C library."""
+    ranks) moves the per-iteration exchange of the fit into the C library.  ``arith``: kmeans.fit_vector."""
     x = x.reshape(-1)
     ops._require_cuda(x, "x", torch.float32)
     n_total = n_min = x.numel()
@@ -150,7 +152,9 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
     if with_cdf is None:
         with_cdf = mode == "density"
     lstats = x_sorted = None
-    if n_min >= _kmeans.SORT_MIN_WEIGHTS:
+    k = 2 ** bits + (1 if mode == "density" else 0)
+    short = arith == "reference" or (arith == "auto" and _kmeans.reference_fit_applies(n_total, k, group))
+    if n_min >= _kmeans.SORT_MIN_WEIGHTS and not short:
         # long vector (every shard of it): one statistics pass and one sort serve the weight distribution, the init and the fit
         lstats = _kmeans.LayerStats(x, n_total, group)
         x_sorted = _kmeans.sorted_copy(x, lstats)
@@ -161,14 +165,18 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         space = np.linspace(np.float32(lstats.min), np.float32(lstats.max), num=2 ** bits).astype(np.float32)
     else:
         space = initial_centroids(x, bits, mode, cdfs, group, n_total)
-    km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min, comm=comm)
-    model, values = km.fit(want_values=want_values)
+    if short:
+        model, values = _kmeans.fit_reference(x, space, want_values=want_values)
+    else:
+        km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min, comm=comm)
+        model, values = km.fit(want_values=want_values)
+    k = int(model.cluster_centers_.size)
     counts = lengths = lhist = total = None
     counts_d = None
     if huffman:
         counts_d = getattr(model, "counts_device_", None)
         if counts_d is None:
-            counts_d = ops.bincount(model.labels_compact_, km.k)
+            counts_d = ops.bincount(model.labels_compact_, k)
         if group is not None:
             sharding.allreduce_sum_(counts_d, group)
     # one host read for what is left on the device: index histogram, sigma / threshold (two float32 carried as one
@@ -181,9 +189,80 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
     if parts:
         host = torch.cat(parts).cpu().numpy()
         if counts_d is not None:
-            counts = host[: km.k].copy()
+            counts = host[:k].copy()
             lengths, lhist, total = ops.huffman_lengths(counts)
         if q is not None:
             sf = host[-2:-1].view(np.float32)
             sigma, thr, nz = float(sf[0]), float(sf[1]), int(host[-1])
     return LayerResult(mask, nz, sigma, thr, values, model, counts, lengths, lhist, total)
+
+
+# ------------------------------------------------------------------ several layers at once
+# A fit is a chain of short dependent launches (a Lloyd iteration on a value-sorted vector touches a few kilobytes), so one
+# layer keeps a handful of the 256 CUs busy; the layers of a model are independent (Trainer.quantize walks them one after the
+# other, common/trainer.py:42-72), so several of them run side by side: one host thread and one HIP stream per worker.
+_POOLS: dict = {}
+_POOL_LOCK = threading.Lock()
+_WORKER = threading.local()
+
+
+def _pool(workers: int) -> ThreadPoolExecutor:
+    with _POOL_LOCK:
+        p = _POOLS.get(workers)
+        if p is None:
+            # kept for the life of the process: the workers' pinned landing zones and streams are made once
+            p = _POOLS[workers] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="nnc-layer")
+        return p
+
+
+def _worker_stream(dev) -> torch.cuda.Stream:
+    st = getattr(_WORKER, "streams", None)
+    if st is None:
+        st = _WORKER.streams = {}
+    if dev not in st:
+        st[dev] = torch.cuda.Stream(device=dev)
+    return st[dev]
+
+
+def compress_layers(layers, workers: int = 4, **kw):
+    """compress_layer for every tensor of ``layers`` (device float32 tensors, each pruned in place when ``q`` is given),
+    ``workers`` of them side by side on streams of their own; the results come back in the order of ``layers`` and are the ones
+    the calls would give one after the other.  Modes that draw from NumPy's global generator (forgy) run one after the other,
+    so that the draws stay in layer order like the reference's.  ``kw``: the arguments of compress_layer (single GPU)."""
+    layers = list(layers)
+    if kw.get("group") is not None:
+        raise ValueError("compress_layers works on whole tensors of one GPU")
+    if workers <= 1 or len(layers) <= 1 or kw.get("mode", "linear") == "forgy":
+        return [compress_layer(t, **kw) for t in layers]
+    dev = layers[0].device
+    main = torch.cuda.current_stream(dev)
+    ready = torch.cuda.Event()
+    ready.record(main)
+    order = sorted(range(len(layers)), key=lambda i: -layers[i].numel())   # long ones first: the tail of the schedule is short ones
+    nxt = iter(order)
+    lock = threading.Lock()
+    results = [None] * len(layers)
+
+    def work():
+        torch.cuda.set_device(dev)
+        s = _worker_stream(dev)
+        s.wait_event(ready)
+        with torch.cuda.stream(s):
+            while True:
+                with lock:
+                    i = next(nxt, None)
+                if i is None:
+                    break
+                results[i] = compress_layer(layers[i], **kw)
+        done = torch.cuda.Event()
+        done.record(s)
+        return done
+
+    futures = [_pool(workers).submit(work) for _ in range(min(workers, len(layers)))]
+    for f in futures:
+        main.wait_event(f.result())
+    for r in results:   # made on a worker's stream, used from here on on the caller's
+        for t in (r.mask, r.values, None if r.model is None else r.model.labels_compact_, None if r.model is None else r.model.counts_device_):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(main)
+    return results

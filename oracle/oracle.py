@@ -316,7 +316,7 @@ def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True, reloc=None, info=Non
         L.orc_dist_own_f32(_p(xc, _f32p), xc.size, _p(c_old, _f32p), _p(labels, _i32p), _p(d, _f32p))
         if reloc is None:
             reloc = "argpartition" if accum == "A" else "descending"
-        if info is not None:
+        if info is not None and np.max(d) != 0:   # (all distances zero: scikit-learn relocates nothing)
             # an exact tie at the selection cut: the samples sklearn takes then depend on numpy's introselect
             ds = np.sort(d)
             info["reloc_events"] = info.get("reloc_events", 0) + 1
@@ -372,11 +372,22 @@ def lloyd_iter(xc, c_old, accum="A", S=0, want_labels=True, reloc=None, info=Non
     return labels, cen, wic.copy(), shift, n_empty
 
 
+DEVICE_REF_NMAX, DEVICE_REF_KMAX = 4096, 128
+
+
+def device_arith(n, k):
+    """(accum, reloc) of the product's single-GPU fit of n weights with k centres: short tensors are fitted in the
+    reference's own arithmetic (mode A sums) with the device's relocation order, everything else in mode B."""
+    return ("A", "descending") if (n <= DEVICE_REF_NMAX and k <= DEVICE_REF_KMAX) else ("B", "descending")
+
+
 def kmeans_lloyd(x, init, accum="A", max_iter=300, tol=1e-4, n_total=None, keep_trace=False, reloc=None):
     """KMeans(n_clusters=K, init=init[:,None], n_init=1, algorithm='full').fit(x[:,None])
-    (utility.py:237-238) -> KMeansResult."""
+    (utility.py:237-238) -> KMeansResult.  accum="device": what device_arith says for this size."""
     x = _f32c(x).ravel()
     n = x.size
+    if accum == "device":
+        accum, reloc = device_arith(n, np.asarray(init).size)
     L = lib()
     # _tolerance (_kmeans.py:279-287): np.mean(np.var(X, axis=0)) * tol, all float32
     tol_ = np.float32(np_var(x) * np.float32(tol))
@@ -426,7 +437,7 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, accum="
         print("not enough bits:", np.prod(layer_weight.shape), " vs ", 2 ** bits)
         return layer_weight, None
     space = init_space(layer_weight, bits, mode, cdfs)
-    km = kmeans_lloyd(layer_weight.reshape(-1), space, accum=accum, reloc=reloc)
+    km = kmeans_lloyd(layer_weight.reshape(-1), space, accum=accum, reloc=reloc)  # accum="device": device_arith
     km.init_space_ = np.asarray(space)
     ris = km.cluster_centers_[km.labels_].reshape(layer_weight.shape)
     return ris, km

@@ -68,7 +68,7 @@ def test_gpt2_small_layer_list_full_pipeline():
     for name in ("h0.b_proj", "h0.ln1", "h0.b_attn", "h0.b_fc", "h3.ln2"):
         w = host[name].copy()
         omask = orc.prune_weigth(w, 1.0, True)
-        ob = orc.kmeans_lloyd(w.ravel(), orc.init_space(w, 4, "linear"), accum="B")
+        ob = orc.kmeans_lloyd(w.ravel(), orc.init_space(w, 4, "linear"), accum="device")  # short tensors: the reference's own sums
         r = res[name]
         assert np.array_equal(r.mask.cpu().numpy().astype(bool).ravel(), omask.ravel()), name
         assert r.model.n_iter_ == ob.n_iter_, (name, r.model.n_iter_, ob.n_iter_)
@@ -91,3 +91,31 @@ def test_gpt2_small_layer_list_full_pipeline():
     diff = np.nonzero(got != want)[0]
     assert diff.size <= 3, diff.size
     assert r.model.n_iter_ >= 2 and r.model.stop_reason_ in ("tol", "strict", "max_iter")
+
+
+def test_layers_side_by_side_equal_one_after_the_other():
+    """pipeline.compress_layers: several layers on streams of their own give what the calls give one after the other."""
+    from neural_network_compression_amd import pipeline
+
+    shapes = [(768,), (768, 768), (2304,), (300, 1000), (3072,), (64, 3, 3, 3), (10,), (200_000,)]
+    host = [synth.weights(s, 7700 + i) for i, s in enumerate(shapes)]
+    kw = dict(q=1.0, bits=4, mode="density", huffman=True, want_values=True)
+    one = [pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), **kw) for w in host]
+    par = pipeline.compress_layers([torch.from_numpy(w.copy()).cuda() for w in host], workers=4, **kw)
+    torch.cuda.synchronize()
+    assert len(par) == len(one)
+    for a, b, s in zip(one, par, shapes):
+        assert (a.model is None) == (b.model is None), s
+        assert a.nzeroed == b.nzeroed and a.sigma == b.sigma and torch.equal(a.mask, b.mask), s
+        if a.model is None:
+            continue
+        assert a.model.n_iter_ == b.model.n_iter_ and np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_), s
+        assert np.array_equal(a.model.labels_, b.model.labels_) and torch.equal(a.values, b.values), s
+        assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits, s
+    # forgy draws from NumPy's global generator: kept in layer order
+    np.random.seed(3)
+    f1 = [pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=1.0, bits=3, mode="forgy") for w in host[:4]]
+    np.random.seed(3)
+    f2 = pipeline.compress_layers([torch.from_numpy(w.copy()).cuda() for w in host[:4]], workers=4, q=1.0, bits=3, mode="forgy")
+    for a, b in zip(f1, f2):
+        assert np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_)

@@ -93,7 +93,7 @@ def test_kmeanspp_mode_against_reference_goldens(util):
     cases, arr = _cases()
     keys = [k for k in sorted(cases) if not cases[k]["passthrough"]]
     assert len(keys) >= 40 and set(PP_BOUNDS) <= set(keys)
-    exact_labels = 0
+    exact_labels = exact_short = 0
     for key in keys:
         c = cases[key]
         w = _input(c["tensor"])
@@ -112,12 +112,18 @@ def test_kmeanspp_mode_against_reference_goldens(util):
         if sha(km.labels_) == c["labels_sha256"]:
             exact_labels += 1
         assert q.shape == w.shape and np.array_equal(q, km.cluster_centers_[km.labels_].reshape(w.shape))
-        # and bit for bit the oracle's order-independent mode from the same draws
+        # and bit for bit the oracle from the same draws (its order-independent mode; short tensors: scikit-learn's own sums)
         np.random.seed(c["seed"])
-        ob = orc.kmeans_plusplus_fit(w.ravel(), c["K"], accum="B")
+        ob = orc.kmeans_plusplus_fit(w.ravel(), c["K"], accum="device")
+        if orc.device_arith(w.size, c["K"])[0] == "A" and not ob.reloc_info_.get("reloc_events", 0):
+            # a short tensor is fitted in the reference's own arithmetic: its centres and indices, bit for bit
+            assert km.arith_ == "reference" and np.array_equal(km.cluster_centers_.ravel(), gc.astype(np.float32)), key
+            assert sha(km.labels_) == c["labels_sha256"], key
+            exact_short += 1
         assert km.n_iter_ == ob.n_iter_ and np.array_equal(km.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), key
         assert np.array_equal(km.labels_, ob.labels_), key
     assert exact_labels >= len(keys) - len(PP_BOUNDS) - 4   # identical centroid indices nearly everywhere
+    assert exact_short >= 8
 
 
 def test_kmeanspp_passthrough_and_device_input(util, capsys):

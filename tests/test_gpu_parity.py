@@ -244,7 +244,8 @@ def test_fit_matches_oracle_mode_b_bit_exact(nnc, gold, key):
         assert km is None and q.shape == w.shape
         return
     init = gold.arr(c["init"])
-    ob = orc.kmeans_lloyd(w.ravel(), init, accum="B")
+    ob = orc.kmeans_lloyd(w.ravel(), init, accum="device")   # mode B; tensors of <= 4096 weights: scikit-learn's own sums
+    assert km.arith_ == ("reference" if orc.device_arith(w.size, c["K"])[0] == "A" else "fixed")
     assert km.n_iter_ == ob.n_iter_, (key, km.n_iter_, ob.n_iter_)
     assert np.array_equal(km.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), key
     assert np.array_equal(km.labels_, ob.labels_), (key, int((km.labels_ != ob.labels_).sum()))
@@ -343,6 +344,11 @@ REF_BOUNDS = {
 REF_TIE_DIVERGENT = {"quant/cfg2/l300.dense1.w/linear4"}
 
 
+# short tensors whose fit relocates SEVERAL empty clusters at once in an order numpy.argpartition leaves undefined (filled in from
+# the GPU run; empty = none)
+REF_SHORT_PAIRING = set()
+
+
 def test_reference_bounds_cover_every_golden_fit(gold):
     fits = {k for k in gold.keys("quant/") if not gold.cases[k]["passthrough"]}
     assert fits == set(REF_BOUNDS) | REF_TIE_DIVERGENT
@@ -365,6 +371,10 @@ def test_fit_against_reference_goldens(nnc, gold, key):
         assert nd <= lab_bound, (key, nd)
     if l1_bound == 0 and lab_bound in (0, None):
         assert sha(km.labels_) == c["labels_sha256"], key   # every centroid index equal to the reference's
+    if km.arith_ == "reference" and key not in REF_SHORT_PAIRING:
+        # tensors of up to 4096 weights are fitted in scikit-learn's own summation order: the reference's centres, bit for bit
+        assert np.array_equal(km.cluster_centers_.ravel(), gc.astype(np.float32).ravel()), key
+        assert sha(km.labels_) == c["labels_sha256"], key
     # the decoded tensor uses the device's own centres
     assert np.array_equal(q, km.cluster_centers_[km.labels_].reshape(w.shape)), key
 

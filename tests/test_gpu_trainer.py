@@ -82,7 +82,7 @@ def test_quantize_matches_oracle_layer_by_layer(trainer_mod, bits, mode, with_cd
             if with_cdf:
                 flat = ref.ravel()
                 cdfs = orc.get_weight_distribution(flat[flat != 0])
-            want, km = orc.get_quantized_weight(ref.copy(), bits=bits, mode=mode, cdfs=cdfs, accum="B")
+            want, km = orc.get_quantized_weight(ref.copy(), bits=bits, mode=mode, cdfs=cdfs, accum="device")
             assert np.array_equal(got.cpu().numpy(), want), (name, ref.shape)
             if km is not None:
                 assert len(np.unique(got.cpu().numpy())) <= km.cluster_centers_.size
@@ -233,7 +233,7 @@ def test_lenet5_trainer_prune_and_quantize_match_oracle(trainer_mod):
         layer = getattr(t.neural_network, name)
         for got, ref, qq in zip(layer.get_weights(), (w.copy(), b.copy()), q[name]):
             orc.prune_weigth(ref, qq, True)
-            want, km = orc.get_quantized_weight(ref.copy(), bits=5, mode="forgy", cdfs=None, accum="B")
+            want, km = orc.get_quantized_weight(ref.copy(), bits=5, mode="forgy", cdfs=None, accum="device")
             assert np.array_equal(got.cpu().numpy(), want), (name, ref.shape)
             assert (km is None) == (ref.size < 33)
 

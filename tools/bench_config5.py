@@ -10,16 +10,20 @@ shapes = synth.gpt2_small_layers()
 dev = torch.device("cuda:0")
 tensors = [(n, torch.from_numpy(synth.weights(s, 5000 + i)).to(dev)) for i, (n, s) in enumerate(shapes)]
 total = sum(t.numel() for _, t in tensors)
-def run():
+def run(workers):
     bits = iters = reloc = 0
-    for _, t in tensors:
-        r = pipeline.compress_layer(t.clone(), q=1.0, bits=4, mode="linear", huffman=True, want_values=True)
+    clones = [t.clone() for _, t in tensors]
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    res = pipeline.compress_layers(clones, workers=workers, q=1.0, bits=4, mode="linear", huffman=True, want_values=True)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    for r in res:
         bits += int(r.total_bits or 0); iters += r.model.n_iter_ if r.model else 0; reloc += r.model.n_relocations_ if r.model else 0
-    return bits, iters, reloc
-run(); torch.cuda.synchronize()
-t0 = time.perf_counter(); bits, iters, reloc = run(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-print(f"{len(tensors)} tensors, {total/1e6:.1f} M weights: {dt*1e3:.1f} ms -> {total/dt/1e9:.2f} G weights/s; {iters} Lloyd iterations, {reloc} relocations, "
-      f"Huffman {bits/total:.3f} bits/weight")
+    return dt, bits, iters, reloc
+for workers in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
+    run(workers)
+    dt, bits, iters, reloc = min(run(workers) for _ in range(3))
+    print(f"workers {workers}: {len(tensors)} tensors, {total/1e6:.1f} M weights: {dt*1e3:.1f} ms -> {total/dt/1e9:.2f} G weights/s; {iters} Lloyd iterations, {reloc} relocations, "
+          f"Huffman {bits/total:.3f} bits/weight", flush=True)
 # per size class (each layer timed on its own, synchronised either side)
 by = {}
 for _, t in tensors:
