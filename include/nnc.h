@@ -193,6 +193,9 @@ typedef struct nnc_kmeans_status {
                             (_k_means_common.pyx:186-187), this library the larger value -- the fits may part ways */
     int32_t reloc_multi; /* relocation events with more than one empty cluster: which far sample goes to which empty cluster
                             is the order numpy.argpartition leaves (implementation defined); here: descending distance */
+    int32_t n_relocated; /* relocation events the device settled without the host (nnc_kmeans_fit enqueues the windowed relocation
+                            behind the iterations of a batch in case they pause; it does nothing when they do not) */
+    int32_t reserved;
 } nnc_kmeans_status;
 
 int32_t nnc_fix_shift(float absmax, int64_t n_total);

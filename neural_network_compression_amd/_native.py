@@ -46,7 +46,7 @@ class KMeansStatus(ctypes.Structure):
     _fields_ = [
         ("iter", c_i32), ("done", c_i32), ("paused", c_i32), ("n_empty", c_i32),
         ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("same_counts", c_i32),
-        ("reloc_ties", c_i32), ("reloc_multi", c_i32),
+        ("reloc_ties", c_i32), ("reloc_multi", c_i32), ("n_relocated", c_i32), ("reserved", c_i32),
     ]
 
 
@@ -141,6 +141,7 @@ DIAG_SIGNATURES = {
     "nnc_debug_set_trace": (c_int, [c_void_p]),
     "nnc_debug_clock": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
+    "nnc_debug_spec_stage": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

@@ -821,6 +821,7 @@ struct KmWs {
     int32_t cur;       // which KmTab / centre set is current
     int32_t glog2, rlog2;
     int32_t reloc_fail; // the windowed farthest-sample selection could not prove its result: redo it the long way
+    int32_t spec_go;    // the relocation chain enqueued behind an iteration "in case" has an event to settle (k_reloc_windows decides)
     float inv;         // cells per unit: cell = (int)((x~ - lo) * inv)
     int32_t cells_pending; // k_finalize left new zones: k_cells has to rebuild tab[cur].cell
     int32_t ku_cur;    // = tab[cur].ku, here so that k_cells learns it in its first round of loads
@@ -1972,6 +1973,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
     // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
     const int st_done = ws->st.done, st_paused = ws->st.paused, st_iter = ws->st.iter, reloc_fail = ws->reloc_fail;
+    const int spec_go = ws->spec_go;
     const int k = ws->p.k, Sft = ws->p.fix_shift, max_iter = ws->p.max_iter, glog2 = ws->glog2;
     const float tol_v = ws->p.tol, p_lo = ws->p.lo, p_hi = ws->p.hi, inv_f = ws->inv;
     const int ku0 = ws->tab[0].ku, ku1 = ws->tab[1].ku;
@@ -1986,6 +1988,9 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         return false;
     }
     if (mode == FIN_FROM_PARTIALS && st_paused && !resume) return false;
+    // the resume behind a relocation chain enqueued "in case": only if that chain had an event to settle (k_reloc_windows, the
+    // head of every such chain, sets the flag either way; nobody clears it here, where waves still on their way would read it)
+    if (resume == 2 && !spec_go) return false;
     if (resume && reloc_fail) { // unproven windowed selection: stay paused, tell the host
         if (tid == 0) ws->st.paused = 2;
         return false;
@@ -2458,9 +2463,10 @@ __global__ void k_cells_prepare(KmWs *__restrict__ ws, int which) { ws->tab[ws->
 
 __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc_kmeans_status *host_st,
                                                       unsigned long long *host_ticket, unsigned long long ticket,
-                                                      int force = 0, int which = 0)
+                                                      int force = 0, int which = 0, int spec = 0)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX];
+    if (spec && !ws->spec_go) return; // (enqueued in case of an empty-cluster event: there is none to settle)
     // the last launch of a batch may carry the host's look-in (nnc_kmeans_iterate_publish): the state is final once
     // k_finalize is through, so the status block and the ticket go out here, without a launch of their own
     if (host_st && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2586,7 +2592,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
         ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
-        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0;
+        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0; ws->st.n_relocated = 0; ws->st.reserved = 0; ws->spec_go = 0;
         ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0; ws->cells_pending = 0;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
@@ -3624,10 +3630,27 @@ __device__ __forceinline__ void block_scan2(long long &a0, long long &a1, long l
 #define KM_SURV_SMALL 384  // ... the cut is refined while there are more than this many
 
 // one workgroup: the window table.  meta = {n_cand, n_windows, bad, window}
-__global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, const KmWs *__restrict__ ws,
+// spec_wmax > 0: the launch was enqueued behind an iteration in case it pauses for an empty cluster (the host does not look in
+// between).  Then the kernel decides by itself whether there is an event it can settle -- paused for empty clusters, not due
+// for the host's strict-convergence check, window (the host's rule, nnc_kmeans_reloc_window) within the scratch -- and says so
+// in ws->spec_go for the launches behind it (k_cells, k_reloc_dist, k_reloc_select, the resumed finalize), which do nothing
+// otherwise.
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws,
                                                               int W, long long cap, KmWin *__restrict__ win, int *__restrict__ meta,
-                                                              unsigned *__restrict__ hist0 = nullptr)
+                                                              unsigned *__restrict__ hist0 = nullptr, int spec_wmax = 0)
 {
+    if (spec_wmax > 0) {
+        const int done = ws->st.done, paused = ws->st.paused, it = ws->st.iter, same = ws->st.same_counts, ne = ws->st.n_empty;
+        long long w = 64;
+        while (w < ne) w *= 2;
+        const bool go = !done && paused == 1 && !(it >= 1 && same) && ne >= 1 && w <= spec_wmax && 2 * w <= n;
+        if (threadIdx.x == 0) {
+            ws->spec_go = go ? 1 : 0;
+            if (go) ws->tab[ws->cur].n_ovf = 0; // (what k_cells_prepare does for the table build behind this launch)
+        }
+        if (!go) return;
+        W = (int)w;
+    }
     if (hist0) for (int i = threadIdx.x; i < 4096; i += KM_THREADS) hist0[i] = 0u; // k_reloc_dist adds to it
     __shared__ long long bnd[2 * KM_THREADS + 2];
     __shared__ long long wst[2 * KM_THREADS], wen[2 * KM_THREADS];
@@ -3712,10 +3735,11 @@ __global__ __launch_bounds__(256) void k_reloc_fill(const float *__restrict__ xs
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restrict__ xs, const KmWin *__restrict__ win,
                                                            const int *__restrict__ meta, float *__restrict__ cand_x,
                                                            float *__restrict__ cand_d, long long cap, const KmWs *__restrict__ ws,
-                                                           unsigned *__restrict__ hist0)
+                                                           unsigned *__restrict__ hist0, int spec = 0)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned h0_s[4096]; // first level of the selection's histogram (top 12 bits of the distance), for free here
+    if (spec && !ws->spec_go) return;
     for (int i = threadIdx.x; i < 4096; i += KM_THREADS) h0_s[i] = 0u;
     if (meta[2]) {
         if (blockIdx.x == 0 && threadIdx.x < 4 && threadIdx.x < cap) { cand_x[threadIdx.x] = 0.0f; cand_d[threadIdx.x] = 0.0f; }
@@ -3786,8 +3810,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restri
 __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
                                                              const float *__restrict__ cand_d, const KmWin *__restrict__ win,
                                                              const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out,
-                                                             int do_relocate, const unsigned *__restrict__ hist0 = nullptr)
+                                                             int do_relocate, const unsigned *__restrict__ hist0 = nullptr, int spec = 0)
 {
+    if (spec) { // enqueued in case of an event: nothing to do without one; the number of empty clusters is the device's
+        if (!ws->spec_go) return;
+        n_empty = ws->st.n_empty;
+    }
     __shared__ __align__(8) unsigned hist[4096];
     __shared__ unsigned long long surv[KM_SURV_MAX];
     __shared__ int wave_i[KM_THREADS / 64];
@@ -4009,6 +4037,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     if (any_bad || !do_relocate) return; // (sharded vector: the ranks first exchange their keys and their verdicts)
     __threadfence_block();
     km_relocate_apply(ws, keys_out, min(m, n_empty + 1), n_empty_ws, &rl);
+    if (spec && tid == 0) ws->st.n_relocated += 1; // (the host did not see this event: it counts them from here)
     RSTAMP(5);
 #undef RSTAMP
 }
@@ -4031,7 +4060,7 @@ static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmea
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
-                       reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
+                       reinterpret_cast<KmWs *>(ws), (int)window, (long long)cap,
                        reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev), hist0);
     LAUNCHCHK("k_reloc_windows");
     // a candidate costs its thread two dependent reads (window record, sample): one or two per thread, not a queue of them
@@ -4051,7 +4080,7 @@ extern "C" int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, cons
     if (!x_sorted || !cand_x_dev || !win_dev || !meta_dev || window < 1) return fail(NNC_EINVAL, "nnc_kmeans_reloc_candidates: bad argument");
     if (cap < 2 * (int64_t)window * (p->k + 1) || cap > 0x7FFFFFFF) return fail(NNC_ENOSPACE, "nnc_kmeans_reloc_candidates: cap must be in [2 * window * (k + 1), 2^31)");
     hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
-                       reinterpret_cast<const KmWs *>(ws), (int)window, (long long)cap,
+                       reinterpret_cast<KmWs *>(ws), (int)window, (long long)cap,
                        reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev));
     LAUNCHCHK("k_reloc_windows");
     const int grid = (int)std::min<int64_t>(256, (cap + 16383) / 16384 + p->k / 4 + 1);
@@ -4129,6 +4158,57 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
     return km_launch_finalize(reinterpret_cast<KmWs *>(ws), p, FIN_FROM_PARTIALS, 1, stream);
 }
 
+// The same chain enqueued behind an iteration IN CASE it pauses for an empty cluster: the host is not looking, the kernels
+// decide (k_reloc_windows) and do nothing when there is no event they can settle.  The scratch is laid out for windows of
+// `wmax`; the look-in of a batch rides on the last launch (the resumed finalize).
+#define KM_SPEC_WMAX 256
+static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans_params *p, void *scratch_dev, void *stream,
+                                void *host_mapped, uint64_t ticket, int stages = 31)
+{
+    const int32_t wmax = KM_SPEC_WMAX;
+    const int64_t cap = reloc_cap(p->k, wmax);
+    unsigned char *b = reinterpret_cast<unsigned char *>(scratch_dev);
+    float *cand_x = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
+    float *cand_d = reinterpret_cast<float *>(b); b += reloc_align((size_t)cap * 4);
+    KmWin *win = reinterpret_cast<KmWin *>(b); b += reloc_align(16 * (size_t)(p->k + 2));
+    int *meta = reinterpret_cast<int *>(b); b += reloc_align(16);
+    long long *keys = reinterpret_cast<long long *>(b); b += reloc_align(8 * (size_t)NNC_KMAX);
+    unsigned *hist0 = reinterpret_cast<unsigned *>(b);
+    int glog2, rlog2;
+    km_defaults(p, &glog2, &rlog2);
+    const size_t lds = km_lds_bytes(p->k, glog2, rlog2, false) + (NNC_KMAX + 2) * sizeof(int);
+    if (lds > 128 * 1024) return fail(NNC_EINVAL, "relocation: search tables too large for the candidate kernel");
+    if (!g_reloc_dist_attr[current_device()].load(std::memory_order_acquire)) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        g_reloc_dist_attr[current_device()].store(1, std::memory_order_release);
+    }
+    if (stages & 1)
+    hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n, w, 0, (long long)cap, win, meta, hist0, (int)wmax);
+    LAUNCHCHK("k_reloc_windows");
+    if (stages & 2)
+    hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, (nnc_kmeans_status *)nullptr,
+                       (unsigned long long *)nullptr, 0ull, 1, 0, 1);
+    LAUNCHCHK("k_cells");
+    // (sized for windows of 64, the common case: the kernel strides over whatever there is)
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (2 * (int64_t)64 * (p->k + 1) + KM_THREADS - 1) / KM_THREADS));
+    if (stages & 4)
+    hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, win, meta, cand_x, cand_d, (long long)cap,
+                       reinterpret_cast<const KmWs *>(w), hist0, 1);
+    LAUNCHCHK("k_reloc_dist");
+    if (stages & 8)
+    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), w, cand_x, cand_d, win, meta, 0, keys, 1, hist0, 1);
+    LAUNCHCHK("k_reloc_select");
+    if (!(stages & 16)) return NNC_OK;
+    return km_launch_finalize(w, p, FIN_FROM_PARTIALS, 2, stream, host_mapped, ticket);
+}
+
+#ifdef NNC_DIAG
+extern "C" int nnc_debug_spec_stage(const float *x_sorted, void *ws, const nnc_kmeans_params *p, void *scratch_dev, int stages, void *stream)
+{
+    return km_launch_spec_reloc(x_sorted, reinterpret_cast<KmWs *>(ws), p, scratch_dev, stream, nullptr, 0, stages);
+}
+#endif
+
 // --------------------------------------------------------------------------------------
 // The Lloyd loop of one fit on one GPU as ONE call: batches of iterations, the look-ins (the status block arrives in pinned
 // host memory, the calling thread polls the ticket), batch sizing from the decay of the centre shift, and the windowed
@@ -4168,18 +4248,44 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
     const bool one_launch = km_one_launch_fit(&p, x_iter);
     const size_t slot = sizeof(nnc_kmeans_status) + 8;
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped); // two slots, used alternately
-    int batch = one_launch ? p.max_iter : 1; // the first iteration is where duplicate initial centres surface as empty clusters
-    int nwin = 0;
+    // Empty clusters come in runs (duplicate initial centres: the bench fit pauses in iterations 0-9, 11, 16, 19), and an event
+    // the host has to see costs a round trip.  So, where the windowed relocation applies, the iterations of a batch are
+    // followed by the relocation chain "in case" (km_launch_spec_reloc: five launches that do nothing without an event), until
+    // a batch goes by without one.
+    const bool spec_ok = sorted && !one_launch && p.prefix_dev && reloc_scratch_dev && (reinterpret_cast<uintptr_t>(reloc_scratch_dev) & 255) == 0 &&
+                         reloc_scratch_bytes >= nnc_kmeans_reloc_scratch_bytes(p.k, KM_SPEC_WMAX) && p.n >= 2 * KM_SPEC_WMAX;
+    bool spec = spec_ok;
+    int batch = one_launch ? p.max_iter : (spec ? 12 : 1); // the first iteration is where duplicate initial centres surface as empty clusters
+    int nwin = 0, nrel_seen = status_out->n_relocated; // (a call after a full-pass relocation carries on from the last status)
+    if (!spec_ok) nrel_seen = 0;
     double s_prev = -1.0, s_last = -1.0;
     int i_prev = 0, i_last = 0;
+    KmWs *w = reinterpret_cast<KmWs *>(ws);
     for (;;) {
         const uint64_t ticket = ++(*ticket_io);
         unsigned char *sl = hb + (ticket & 1) * slot;
-        if ((rc = nnc_kmeans_iterate_publish(x_iter, ws, &p, batch, sl, ticket, stream))) return rc;
+        if (spec) {
+            if ((rc = km_set_lds_attr())) return rc;
+            for (int i = 0; i < batch; i++) {
+                if ((rc = km_launch_accumulate(x_iter, w, &p, stream))) return rc;
+                if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream))) return rc;
+                if ((rc = km_launch_spec_reloc(x_iter, w, &p, reloc_scratch_dev, stream, i == batch - 1 ? sl : nullptr, ticket))) return rc;
+            }
+        } else if ((rc = nnc_kmeans_iterate_publish(x_iter, ws, &p, batch, sl, ticket, stream))) return rc;
         if ((rc = km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(sl + sizeof(nnc_kmeans_status)), ticket, S(stream)))) return rc;
         const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
         *status_out = st;
+        const int dev_events = spec_ok ? st.n_relocated - nrel_seen : 0; // events the device settled by itself in this batch
+        nrel_seen = st.n_relocated;
+        nwin += dev_events;
         if (st.done) break;
+        if (spec && !st.paused) {
+            // a chain that finds nothing to do still costs its five launches (about as much as the round trip it would have saved):
+            // carry on only while most iterations pause
+            if (2 * dev_events >= batch) { batch = 4; s_prev = s_last = -1.0; continue; }
+            spec = false; // back to plain iterations, sized by the decay of the shift
+            s_prev = s_last = -1.0;
+        }
         if (st.paused) {
             const bool strict_check = st.iter >= 1 && st.same_counts;
             const int32_t window = (sorted && st.paused == 1 && !strict_check) ? nnc_kmeans_reloc_window(p.n, st.n_empty) : 0;

@@ -575,6 +575,12 @@ class DeviceKMeans:
             # comes back when the fit has stopped or an empty-cluster event needs the full-pass relocation
             st = nat.KMeansStatus()
             nwin = ctypes.c_int32(0)
+            if self.sorted_everywhere and self.reloc == "auto" and not self.one_launch and self.prefix is not None and self.n >= 512:
+                # room for the relocation chain the library enqueues behind the first iterations in case they pause for
+                # empty clusters (windows of up to 256 samples: include/nnc.h, nnc_kmeans_fit)
+                need = int(self.L.nnc_kmeans_reloc_scratch_bytes(self.k, 256))
+                if self._reloc_scratch is None or self._reloc_scratch.numel() < need:
+                    self._reloc_scratch = torch.empty(need, dtype=torch.uint8, device=self.dev)
             while True:
                 scratch = self._reloc_scratch
                 nat.check(self.L.nnc_kmeans_fit(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), self.batch,

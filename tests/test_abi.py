@@ -47,7 +47,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 def test_struct_layouts():
     assert ctypes.sizeof(nat.KMeansParams) == 64
-    assert ctypes.sizeof(nat.KMeansStatus) == 40
+    assert ctypes.sizeof(nat.KMeansStatus) == 48
 
 
 def test_fix_shift_rule(lib):
