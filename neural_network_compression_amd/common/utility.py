@@ -89,19 +89,21 @@ def prune_weigth(original_weigth, threshold=0.25, std_smooth=True):
 
 # ------------------------------------------------------------------------------------------
 def _cdf_from_counts(steps: np.ndarray, counts: np.ndarray):
-    """utility.py:374-392 on the 32 steps and the 31 integer bin counts (host, 31 values)."""
-    from scipy.interpolate import interp1d
-
+    """utility.py:374-392 on the 32 steps and the 31 integer bin counts (host, 31 values): normalised counts, their running
+    float64 sum, divided by its last entry, then scipy.interpolate.interp1d(x, cdf, "linear") at 300 points -- its
+    ``_call_linear`` spelled out with the same dtypes (x and the 300 points float32, the cdf float64), which gives the same
+    bits without building the interpolator object (tests/test_abi.py::test_cdf_from_counts_is_scipys)."""
     x = steps[:-1]
-    tot_counter = np.array([int(c) for c in counts]) / (np.sum([int(c) for c in counts]))
-    cdf = []
-    for i in range(len(tot_counter)):
-        cdf.append(tot_counter[i] if i == 0 else tot_counter[i] + cdf[i - 1])
-    cdf = np.array(cdf)
+    c = np.asarray(counts, dtype=np.int64)
+    tot_counter = c / np.sum(c)          # int / int -> float64
+    cdf = np.cumsum(tot_counter)         # sequential float64 adds, as the reference's python loop
     cdf = cdf / cdf[-1]
-    xnew = np.linspace(min(x), max(x), 300)
-    spl = interp1d(x, cdf, "linear")
-    return xnew, spl(xnew)
+    xnew = np.linspace(x.min(), x.max(), 300)
+    idx = np.searchsorted(x, xnew).clip(1, len(x) - 1).astype(int)
+    lo, hi = idx - 1, idx
+    x_lo, y_lo = x[lo], cdf[lo]
+    slope = (cdf[hi] - y_lo) / (x[hi] - x_lo)
+    return xnew, slope * (xnew - x_lo) + y_lo
 
 
 def _weight_distribution_device(x: torch.Tensor, skip_zeros: bool):
@@ -142,7 +144,7 @@ def _init_space(x: torch.Tensor, n: int, bits: int, mode: str, cdfs):
         tmp = np.linspace(0, 1, num=(2 ** bits) + 1)
         xval, yval = np.asarray(cdfs[0]), np.asarray(cdfs[1], dtype=np.float64)
         idx = np.abs(yval[None, :] - tmp[:, None]).argmin(axis=1)
-        return np.array([xval[i] for i in idx])
+        return xval[idx]
     if mode == "forgy":
         # np.random.choice(flat, size=K) draws K indices with the legacy global RNG
         # (randint(0, N, K)) and gathers; draw the same indices, gather on the device

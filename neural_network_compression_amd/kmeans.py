@@ -49,6 +49,7 @@ class QuantizedModel:
         self.stop_reason_ = stop
         self._labels_np = None
         self.counts_device_ = None   # int64[K] index histogram of labels_ (this rank's shard), device
+        self.counts_host_ = None     # the same on the host, where the fit's one host read brought it along
 
     def labels_device(self) -> torch.Tensor:
         """int32 centroid indices on the device."""
@@ -80,6 +81,14 @@ def _pinned_landing():
     if getattr(_TLS, "stats", None) is None:
         _TLS.stats = (torch.empty(6, dtype=torch.float32, pin_memory=True), torch.empty(2, dtype=torch.int64, pin_memory=True))
     return _TLS.stats
+
+
+def _prune_landing():
+    """One pinned float32[2] + int64[1] per host thread for what the prune step leaves on the device (sigma, threshold, number
+    of zeroed weights): copied out asynchronously right behind the prune kernels, read after the layer's last host read."""
+    if getattr(_TLS, "prune", None) is None:
+        _TLS.prune = (torch.empty(2, dtype=torch.float32, pin_memory=True), torch.empty(1, dtype=torch.int64, pin_memory=True))
+    return _TLS.prune
 
 
 def _status_landing(nbytes: int) -> torch.Tensor:
@@ -187,20 +196,22 @@ def fit_reference(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = 
     if not reference_fit_applies(n, k):
         raise ValueError(f"fit_reference: n={n}, k={k} outside k <= n <= {REF_NMAX}, k <= {REF_KMAX}")
     dev, stream = x.device, ops._stream(x)
-    init_d = torch.from_numpy(init).to(dev)
+    init_d = ops.small_to_device(init, dev)
     lab = torch.empty(n, dtype=torch.uint8, device=dev)
     vals = torch.empty(n, dtype=torch.float32, device=dev) if want_values else None
     # one device block for everything the host reads back: centres (k float32), result (8 x 4 bytes; the diagnostic build
     # appends 8 int64 phase times)
     kp = (k + 1) & ~1
-    back = torch.empty(kp + 8 + 16, dtype=torch.float32, device=dev)
-    counts = torch.empty(k, dtype=torch.int64, device=dev)
+    blk = torch.empty(8 * k + 4 * (kp + 8 + 16), dtype=torch.uint8, device=dev)   # index histogram (k int64) in front
+    counts, back = blk[: 8 * k].view(torch.int64), blk[8 * k:].view(torch.float32)
     nat.check(L.nnc_kmeans_fit_reference_f32(x.data_ptr(), n, init_d.data_ptr(), k, int(max_iter), float(tol), lab.data_ptr(), ops._ptr(vals),
                                              back.data_ptr(), counts.data_ptr(), back.data_ptr() + 4 * kp, stream))
-    host = back.cpu().numpy()
+    hostb = blk.cpu().numpy()
+    host = hostb[8 * k:].view(np.float32)
     res = host[kp: kp + 8].view(np.int32)
     model = QuantizedModel(host[:k].copy(), lab, int(res[0]), int(res[2]), {1: "tol", 2: "max_iter", 3: "strict"}.get(int(res[1]), "?"))
     model.counts_device_ = counts
+    model.counts_host_ = hostb[: 8 * k].view(np.int64).copy()
     model.n_reloc_windowed_ = 0
     model.reloc_tie_ = int(res[3])
     model.n_reloc_multi_ = int(res[4])
@@ -284,7 +295,7 @@ class DeviceKMeans:
                                   x_mean=float(mean), tol=float(self.tol_), lo=float(lo), hi=float(hi))
         self.ws_bytes = self.L.nnc_kmeans_workspace_bytes(self.k)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
-        init_d = torch.from_numpy(init).to(self.dev)
+        init_d = ops.small_to_device(init, self.dev)
         nat.check(self.L.nnc_kmeans_init(self.ws.data_ptr(), self.ws_bytes, ctypes.byref(self.p), init_d.data_ptr(), self.stream))
         pptr = self.L.nnc_kmeans_partials(self.ws.data_ptr())
         # view of the device partials (2K int64) inside the workspace, for the all-reduce / relocation edits
@@ -419,8 +430,9 @@ class DeviceKMeans:
                                            ops._ptr(lab), lb, ops._ptr(q), ops._ptr(d), ops._ptr(dist_hist), self.stream))
         return lab, q, d
 
-    def centers_device(self, which: int = 0, centred: bool = False) -> torch.Tensor:
-        out = torch.empty(self.k, dtype=torch.float32, device=self.dev)
+    def centers_device(self, which: int = 0, centred: bool = False, out: torch.Tensor | None = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty(self.k, dtype=torch.float32, device=self.dev)
         nat.check(self.L.nnc_kmeans_get_centers(self.ws.data_ptr(), int(which), 1 if centred else 0, out.data_ptr(), self.stream))
         return out
 
@@ -623,7 +635,10 @@ class DeviceKMeans:
             strict_labels = self.assign(which=1, labels=True)[0]
         stop = {1: "tol", 2: "max_iter", 3: "strict"}.get(int(st.done), "?")
         n_iter = int(st.iter)
-        cen_d = self.centers_device(which=0, centred=False)
+        # one device block for what the host reads at the end: index histogram (k int64), centres (k float32)
+        blk = torch.empty(12 * self.k, dtype=torch.uint8, device=self.dev)
+        counts, cen_d = blk[: 8 * self.k].view(torch.int64), blk[8 * self.k:].view(torch.float32)
+        self.centers_device(which=0, centred=False, out=cen_d)
         if strict_labels is not None:
             # label-equality stop: scikit-learn keeps the labels of that iteration and does
             # not run another E-step (_kmeans.py:717-722, 736)
@@ -635,12 +650,12 @@ class DeviceKMeans:
         else:
             lab, vals, _ = self.assign(which=0, labels=True, values=want_values)
         # index histogram of these labels (this rank's shard), from one more pass over the iteration copy
-        counts = torch.empty(self.k, dtype=torch.int64, device=self.dev)
         nat.check(self.L.nnc_kmeans_label_counts(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
                                                  1 if strict_labels is not None else 0, counts.data_ptr(), self.stream))
-        centers = cen_d.cpu().numpy()   # the one host read of the epilogue, behind everything that was enqueued
-        model = QuantizedModel(centers, lab, n_iter, self.n_relocations, stop)
+        host = blk.cpu().numpy()   # the one host read of the epilogue, behind everything that was enqueued
+        model = QuantizedModel(host[8 * self.k:].view(np.float32).copy(), lab, n_iter, self.n_relocations, stop)
         model.counts_device_ = counts
+        model.counts_host_ = host[: 8 * self.k].view(np.int64).copy()   # (this rank's shard of the vector)
         model.n_reloc_windowed_ = self.n_reloc_windowed   # relocation events settled without a pass over the vector
         # what scikit-learn leaves to numpy.argpartition (include/nnc.h, nnc_kmeans_status): events in which two different
         # samples tied at the selection cut (the fits may part ways there), events with more than one empty cluster

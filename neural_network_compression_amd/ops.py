@@ -8,6 +8,7 @@ streams); the arithmetic is in the HIP kernels.  There is no CPU fallback.
 from __future__ import annotations
 
 import ctypes
+import threading
 import math
 
 import numpy as np
@@ -27,6 +28,35 @@ def _require_cuda(t: torch.Tensor, name: str, dtype=None):
 
 def _stream(t: torch.Tensor) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+_STAGE = threading.local()
+_STAGE_SLOTS, _STAGE_BYTES = 16, 8192
+
+
+def small_to_device(arr: np.ndarray, dev) -> torch.Tensor:
+    """A few kilobytes of host data (initial centres, histogram steps) to the device without the blocking staging copy a pageable
+    source costs: through a ring of pinned slots of this host thread, asynchronously on the current stream.  A slot is reused
+    only after the copy that last read it has completed (an event per slot)."""
+    arr = np.ascontiguousarray(arr)
+    nb = arr.nbytes
+    if nb == 0 or nb > _STAGE_BYTES:
+        return torch.from_numpy(arr).to(dev)
+    ring = getattr(_STAGE, "ring", None)
+    if ring is None:
+        ring = _STAGE.ring = {"buf": torch.empty(_STAGE_SLOTS * _STAGE_BYTES, dtype=torch.uint8, pin_memory=True),
+                              "ev": [None] * _STAGE_SLOTS, "next": 0}
+    i = ring["next"]
+    ring["next"] = (i + 1) % _STAGE_SLOTS
+    if ring["ev"][i] is not None:
+        ring["ev"][i].synchronize()
+    slot = ring["buf"][i * _STAGE_BYTES: i * _STAGE_BYTES + nb]
+    slot.numpy()[:] = arr.view(np.uint8).reshape(-1)
+    out = torch.empty(nb, dtype=torch.uint8, device=dev)
+    out.copy_(slot, non_blocking=True)
+    ev = ring["ev"][i] = ring["ev"][i] or torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return out.view(torch.from_numpy(arr).dtype).reshape(arr.shape)
 
 
 def _ptr(t) -> int:

@@ -74,7 +74,7 @@ def weight_distribution_sorted(x_sorted: torch.Tensor, stats, group=None):
         raise ValueError("zero-size array to reduction operation minimum which has no identity")
     steps = np.linspace(np.float32(stats.min_nonzero), np.float32(stats.max_nonzero), num=32)  # float32 under NumPy 2
     steps32 = np.ascontiguousarray(steps, dtype=np.float32)
-    steps_d = torch.from_numpy(steps32).to(x_sorted.device)
+    steps_d = ops.small_to_device(steps32, x_sorted.device)
     from . import _native as nat
 
     t = torch.empty(33, dtype=torch.int64, device=x_sorted.device)   # 32 ranks: #{w < steps[b]} in this shard; then this shard's zeros
@@ -141,8 +141,13 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         sizes = torch.cat(sizes).cpu().numpy()
         n_total, n_min = int(sizes.sum()), int(sizes.min())
     mask = nz = sigma = thr = None
+    early = None
     if q is not None:
         mask, stats, nzt = prune_sharded_(x, q, std_smooth, group, n_total)
+        if group is None:
+            early = _kmeans._prune_landing()
+            early[0].copy_(stats.reshape(-1)[:2], non_blocking=True)
+            early[1].copy_(nzt.reshape(-1)[:1], non_blocking=True)
     if n_total < (2 ** bits) + 1:
         print("not enough bits:", n_total, " vs ", 2 ** bits)
         if q is not None:
@@ -172,28 +177,24 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         model, values = km.fit(want_values=want_values)
     k = int(model.cluster_centers_.size)
     counts = lengths = lhist = total = None
-    counts_d = None
     if huffman:
-        counts_d = getattr(model, "counts_device_", None)
-        if counts_d is None:
-            counts_d = ops.bincount(model.labels_compact_, k)
-        if group is not None:
-            sharding.allreduce_sum_(counts_d, group)
-    # one host read for what is left on the device: index histogram, sigma / threshold (two float32 carried as one
-    # int64), number of zeroed weights
-    parts = []
-    if counts_d is not None:
-        parts.append(counts_d.reshape(-1))
+        counts = getattr(model, "counts_host_", None) if group is None else None   # came along with the fit's host read
+        if counts is None:
+            counts_d = getattr(model, "counts_device_", None)
+            if counts_d is None:
+                counts_d = ops.bincount(model.labels_compact_, k)
+            if group is not None:
+                sharding.allreduce_sum_(counts_d, group)
+            counts = counts_d.cpu().numpy()
+        lengths, lhist, total = ops.huffman_lengths(counts)
     if q is not None:
-        parts += [stats.reshape(-1)[:2].contiguous().view(torch.int64), nzt.reshape(-1)[:1]]
-    if parts:
-        host = torch.cat(parts).cpu().numpy()
-        if counts_d is not None:
-            counts = host[:k].copy()
-            lengths, lhist, total = ops.huffman_lengths(counts)
-        if q is not None:
-            sf = host[-2:-1].view(np.float32)
-            sigma, thr, nz = float(sf[0]), float(sf[1]), int(host[-1])
+        if early is not None:
+            # sigma / threshold / number of zeroed weights left the device right behind the prune kernels; the fit's host read
+            # (a synchronisation of this stream) lies behind them
+            sigma, thr, nz = float(early[0][0]), float(early[0][1]), int(early[1][0])
+        else:
+            sf = stats.reshape(-1)[:2].cpu().numpy()
+            sigma, thr, nz = float(sf[0]), float(sf[1]), int(nzt.item())
     return LayerResult(mask, nz, sigma, thr, values, model, counts, lengths, lhist, total)
 
 
