@@ -250,7 +250,12 @@ int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params
  * relocates, resumes (nnc_kmeans_finalize(ws, 1)) and calls again.  host_mapped: 2 * (sizeof(nnc_kmeans_status) + 8) bytes
  * of host memory the device can write (see nnc_kmeans_status_publish); *ticket_io: a counter that never repeats for this
  * buffer; sorted: x_iter is in ascending order (windowed relocation allowed); reloc_scratch_dev: as for
- * nnc_kmeans_relocate_windowed (may be NULL); *n_windowed_out: relocation events settled inside.  The calling thread polls. */
+ * nnc_kmeans_relocate_windowed (may be NULL); *n_windowed_out: relocation events settled inside.  The calling thread polls.
+ * Empty clusters come in runs (duplicate initial centres): when the scratch holds windows of 256 samples
+ * (nnc_kmeans_reloc_scratch_bytes(k, 256)) the iterations of the first batches are followed by the windowed relocation "in
+ * case" -- its launches read the status themselves and do nothing without an event they can settle -- so that such events
+ * cost no look-in; status_out->n_relocated counts them (included in *n_windowed_out).  status_out is read on entry (pass a
+ * zeroed block for a new fit, the block of the previous call when calling again). */
 int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_params *p, int32_t max_batch, int32_t sorted,
                    void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped, uint64_t *ticket_io,
                    nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream);
