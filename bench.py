@@ -139,8 +139,23 @@ def main():
     n_total = args.n * world if args.scaling == "weak" else args.n
     lo, hi = sharding.shard_bounds(n_total, world, rank)
     comm = None
+    comm_note = None
     if group is not None and args.backend == "nccl" and not args.python_exchange:
-        comm = sharding.RcclComm(group, dev)   # the library's own RCCL communicator: the exchange is enqueued from C
+        # the library's own RCCL communicator: the exchange is enqueued from C.  Every rank must end up on the same path, so the
+        # ranks agree on whether it came up; if it did not anywhere, the exchange goes through torch.distributed and the line says so.
+        import torch.distributed as dist
+
+        try:
+            comm = sharding.RcclComm(group, dev)
+        except Exception as e:  # noqa: BLE001 - reported in the JSON line and on stderr
+            comm_note = f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: library communicator unavailable ({comm_note}); falling back to torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            comm_note = comm_note or "another rank could not create it"
     w_host = synth.weights((hi - lo,), SEED, start=lo)
     w0 = torch.from_numpy(w_host).to(dev)
 
@@ -265,7 +280,7 @@ def main():
                 "workload": f"configs[3]: synthetic {(hi - lo)/1e6:g} M fp32 weights per GPU ({n_total/1e6:g} M total), "
                             f"prune q={args.q} sigma -> CDF -> {args.mode}-init k-means bits={args.bits} "
                             f"(K={k_fit}) to convergence -> labels+values -> Huffman lengths",
-                "weights_per_gpu": hi - lo, "exchange": ("rccl-in-library" if comm is not None else ("torch.distributed" if world > 1 else None)),
+                "weights_per_gpu": hi - lo, "exchange": ("rccl-in-library" if comm is not None else (("torch.distributed" + (f" (library communicator unavailable: {comm_note})" if comm_note else "")) if world > 1 else None)),
                 "k": k_fit, "lloyd_iterations": int(n_iter), "stop": res.model.stop_reason_ if res.model else None,
                 "relocations": int(res.model.n_relocations_) if res.model else 0,
                 "relocation_ties": int(getattr(res.model, "reloc_tie_", 0)) if res.model else 0,
