@@ -1350,6 +1350,83 @@ __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
     return hp->val[1];
 }
 
+// The same tree by ONE wave on its own (n <= 2048: at most 32 leaves), wave-level LDS fences instead of workgroup barriers:
+// for the K-sized sums of the finalize step, where sixteen waves meeting at eight barriers cost more than the arithmetic.
+// Every lane of the calling wave returns the sum; the other waves of the workgroup must not touch *hp meanwhile.
+template <typename F>
+__device__ float wave_pairwise_sum(F elem, int n, PwHeap *hp)
+{
+    const int lane = threadIdx.x & 63;
+    if (n <= LEAF) {
+        if (lane < 8) {
+            float res = 0.0f;
+            if (n < 8) {
+                for (int i = 0; i < n; i++) res += elem(i);
+            } else {
+                float r = elem(lane);
+                const int lim = n - (n % 8);
+                for (int i = 8; i < lim; i += 8) r += elem(i + lane);
+                r = r + __shfl_xor(r, 1);
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                res = r;
+                for (int i = lim; i < n; i++) res += elem(i);
+            }
+            if (lane == 0) hp->val[1] = res;
+        }
+        wave_lds_fence();
+        return hp->val[1];
+    }
+    hp->start[lane] = 0; hp->len[lane] = 0; hp->val[lane] = 0.0f;
+    wave_lds_fence();
+    if (lane == 0) { hp->start[1] = 0; hp->len[1] = n; }
+    wave_lds_fence();
+    int depth = 0;
+    while (depth < 5 && ((n + (1 << depth) - 1) >> depth) > LEAF) depth++;
+    if (depth < 5) depth++; // rounding to multiples of 8 can push one child just over the leaf size
+    for (int lev = 0; lev < depth; lev++) {
+        const int i = (1 << lev) + lane;
+        if (lane < (1 << lev)) {
+            const int l = hp->len[i];
+            if (l > LEAF) {
+                int n2 = l / 2; n2 -= n2 % 8;
+                hp->start[2 * i] = hp->start[i]; hp->len[2 * i] = n2;
+                hp->start[2 * i + 1] = hp->start[i] + n2; hp->len[2 * i + 1] = l - n2;
+            }
+        }
+        wave_lds_fence();
+    }
+    const int j8 = lane & 7;
+    for (int node = 1 + (lane >> 3); node < (2 << depth) && node < 64; node += 8) {
+        const int l = hp->len[node];
+        if (l > 0 && l <= LEAF) {
+            const int st = hp->start[node];
+            float res;
+            if (l < 8) {
+                res = 0.0f;
+                for (int i = 0; i < l; i++) res += elem(st + i);
+            } else {
+                float r = elem(st + j8);
+                const int lim = l - (l % 8);
+                for (int i = 8; i < lim; i += 8) r += elem(st + i + j8);
+                r = r + __shfl_xor(r, 1);
+                r = r + __shfl_xor(r, 2);
+                r = r + __shfl_xor(r, 4);
+                res = r;
+                for (int i = lim; i < l; i++) res += elem(st + i);
+            }
+            if (j8 == 0) hp->val[node] = res;
+        }
+    }
+    wave_lds_fence();
+    for (int lev = depth - 1; lev >= 0; lev--) {
+        const int i = (1 << lev) + lane;
+        if (lane < (1 << lev) && hp->len[i] > LEAF) hp->val[i] = hp->val[2 * i] + hp->val[2 * i + 1];
+        wave_lds_fence();
+    }
+    return hp->val[1];
+}
+
 
 // ---- the rank-boundary iteration (value-sorted vector + block prefix sums) ---------------------
 //
@@ -2102,7 +2179,10 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             }
         }
         FIN_SYNC();
-        const float tot = block_pairwise_sum<ONEWAVE>([&](int i) { return sq[i]; }, k, &heap);
+        // (NumPy's pairwise sum of the k squared shifts: by the first wave on its own, the others go on)
+        float tot = 0.0f;
+        if (ONEWAVE) tot = block_pairwise_sum<true>([&](int i) { return sq[i]; }, k, &heap);
+        else if (tid < 64) tot = wave_pairwise_sum([&](int i) { return sq[i]; }, k, &heap);
         if (tid == 0) {
             int iter = st_iter + 1;
             int done = 0;
@@ -2141,6 +2221,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                 }
             }
         }
+        FSTAMP(12);
         still_sorted = FIN_AND(ok);
         // nearly sorted (two neighbours changed places): a few odd-even transposition passes repair it
         for (int pass = 0; pass < 3 && !still_sorted; pass++) {

@@ -8,7 +8,7 @@ from neural_network_compression_amd import kmeans, ops, pipeline, synth
 
 dev = torch.device("cuda:0")
 L = nat.load()
-order = [(0, "start"), (1, "shards->partials"), (2, "empties+average"), (3, "shift+tol+state"), (8, "still-sorted"), (9, "rank sort"),
+order = [(0, "start"), (1, "shards->partials"), (2, "empties+average"), (3, "shift+tol+state"), (12, "perm filled"), (8, "still-sorted"), (9, "rank sort"),
          (10, "distinct"), (4, "tables"), (11, "zones raw"), (5, "zone scans"), (7, "end")]
 for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
     x = torch.from_numpy(synth.weights((n,), 4000)).to(dev)
