@@ -3707,6 +3707,9 @@ __device__ __forceinline__ void block_scan2(long long &a0, long long &a1, long l
 }
 
 #define KM_RELOC_WMAX 8192 // a window side never grows beyond this many samples
+#ifndef KM_RELOC_WMIN
+#define KM_RELOC_WMIN 64  // smallest window side (16 was tried: the proof fails more often and the full pass it falls back to costs a millisecond)
+#endif
 #define KM_SURV_MAX 2048   // survivors of the histogram cut that are ranked exactly
 #define KM_SURV_SMALL 384  // ... the cut is refined while there are more than this many
 
@@ -3722,7 +3725,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__res
 {
     if (spec_wmax > 0) {
         const int done = ws->st.done, paused = ws->st.paused, it = ws->st.iter, same = ws->st.same_counts, ne = ws->st.n_empty;
-        long long w = 64;
+        long long w = KM_RELOC_WMIN;
         while (w < ne) w *= 2;
         const bool go = !done && paused == 1 && !(it >= 1 && same) && ne >= 1 && w <= spec_wmax && 2 * w <= n;
         if (threadIdx.x == 0) {
@@ -4198,7 +4201,7 @@ static size_t reloc_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" int32_t nnc_kmeans_reloc_window(int64_t n, int32_t n_empty)
 {
-    int64_t w = 64;
+    int64_t w = KM_RELOC_WMIN;
     while (w < n_empty) w *= 2;
     if (n_empty < 1 || w > 1024 || 2 * w > n) return 0; // not applicable: use the full pass
     return (int32_t)w;
