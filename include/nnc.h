@@ -379,6 +379,61 @@ int nnc_kmeans_fit_reference_f32(const float *x, int32_t n, const float *centers
                                  void *result_dev, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * One layer tensor through the whole path as ONE host call: what Trainer._prune_parameters (common/trainer.py:177-193) and
+ * Trainer.quantize (common/trainer.py:42-72) do to one tensor -- prune_weigth, get_weight_distribution of the non-zeros,
+ * get_quantized_weight (modes "linear" and "density") -- plus the index histogram and Huffman code lengths.  Everything
+ * above stays available step by step; this call only strings the steps together, with the K-sized host arithmetic of
+ * utility.py (np.linspace, the cumulative distribution and its interp1d, the density init) restated in the reference's
+ * order of float32 / float64 operations (the nnc_host_* functions, callable on their own and without a device).
+ * The calling thread waits three times (statistics, bin counts, the K-sized results) and polls the fit's look-ins; several
+ * host threads may run layers side by side, each with its own stream, workspace and host block.
+ *   x           : n float32 on the device, pruned IN PLACE when p->prune
+ *   mask_out    : n bytes (p->prune), labels_out: n uint8 (k <= 256) or uint16, values_out: n float32 (p->want_values)
+ *   ws_dev      : nnc_compress_layer_workspace_bytes(n, k) device bytes; host_pinned: nnc_compress_layer_host_bytes() bytes of
+ *                 host memory the device can write (hipHostMalloc / pinned), 8-byte aligned; *ticket_io: a counter kept
+ *                 with that host block (never reset)
+ *   result      : host struct; status NNC_LAYER_DONE, or NNC_LAYER_HOST: the tensor has been pruned (mask, sigma, threshold,
+ *                 n_zeroed are valid) but the fit needs the caller's step-by-step path (short tensor with density init,
+ *                 fewer than 512 weights with more than 128 centroids, full-pass relocation, strict-convergence check).
+ * ---------------------------------------------------------------------------------- */
+#define NNC_INIT_LINEAR 0
+#define NNC_INIT_DENSITY 1
+#define NNC_LAYER_DONE 0
+#define NNC_LAYER_HOST 1
+#define NNC_ARITH_FIXED 0
+#define NNC_ARITH_REFERENCE 1
+typedef struct nnc_layer_params {
+    float q;              /* prune_weigth's q (float32) */
+    int32_t prune;        /* 0: leave x as it is */
+    int32_t std_smooth;   /* threshold = std(x) * q, else q */
+    int32_t bits;         /* 2**bits centroids (+ 1 for density) */
+    int32_t mode;         /* NNC_INIT_LINEAR / NNC_INIT_DENSITY */
+    int32_t want_values;  /* write cluster_centers_[labels_] to values_out */
+    int32_t reserved[2];
+} nnc_layer_params;
+typedef struct nnc_layer_result {
+    int32_t status, k, label_bytes, arith;
+    int32_t n_iter, stop, n_relocations, n_reloc_windowed, reloc_ties, reloc_multi;
+    float sigma, threshold;
+    int64_t n_zeroed, total_bits;
+    float centers[NNC_KMAX];        /* cluster_centers_ */
+    int64_t counts[NNC_KMAX];       /* index histogram */
+    uint8_t code_lengths[NNC_KMAX]; /* Huffman code length per index */
+} nnc_layer_result;
+size_t nnc_compress_layer_workspace_bytes(int64_t n, int32_t k);
+size_t nnc_compress_layer_host_bytes(void);
+int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_params *p, uint8_t *mask_out, void *labels_out, float *values_out,
+                           void *ws_dev, size_t ws_bytes, void *host_pinned, size_t host_bytes, uint64_t *ticket_io,
+                           nnc_layer_result *result, void *stream);
+/* np.linspace(start, stop, num) for float32 scalars (NumPy >= 2), bit for bit (common/utility.py:208, 365) */
+int nnc_host_linspace_f32(float start, float stop, int32_t num, float *out);
+/* (xnew[300] float32, cdf[300] float64) = get_weight_distribution's host part (common/utility.py:374-392) from the 32 steps
+ * and the 31 bin counts */
+int nnc_host_cdf(const float *steps32, const int64_t *counts31, float *xnew300, double *cdf300);
+/* the density init (common/utility.py:211-221): 2**bits + 1 float32 centroids from that curve */
+int nnc_host_density_init(const float *xnew300, const double *cdf300, int32_t bits, float *space_out);
+
+/* ------------------------------------------------------------------------------------
  * k-means++ seeding: the reference's 4th initialisation mode, get_quantized_weight(mode="kmeans++") =
  * KMeans(n_clusters=2**bits).fit(...) (common/utility.py:228-232) -> scikit-learn's _kmeans_plusplus
  * (cluster/_kmeans.py:163-253) on the mean-centred float32 weights.  The host draws the random numbers from NumPy's

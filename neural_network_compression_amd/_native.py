@@ -50,6 +50,21 @@ class KMeansStatus(ctypes.Structure):
     ]
 
 
+class LayerParams(ctypes.Structure):
+    _fields_ = [("q", c_f32), ("prune", c_i32), ("std_smooth", c_i32), ("bits", c_i32), ("mode", c_i32), ("want_values", c_i32),
+                ("reserved", c_i32 * 2)]
+
+
+class LayerResult(ctypes.Structure):
+    _fields_ = [
+        ("status", c_i32), ("k", c_i32), ("label_bytes", c_i32), ("arith", c_i32),
+        ("n_iter", c_i32), ("stop", c_i32), ("n_relocations", c_i32), ("n_reloc_windowed", c_i32), ("reloc_ties", c_i32), ("reloc_multi", c_i32),
+        ("sigma", c_f32), ("threshold", c_f32),
+        ("n_zeroed", c_i64), ("total_bits", c_i64),
+        ("centers", c_f32 * NNC_KMAX), ("counts", c_i64 * NNC_KMAX), ("code_lengths", ctypes.c_uint8 * NNC_KMAX),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/nnc.h declares
 SIGNATURES = {
     "nnc_version": (c_int, []),
@@ -106,6 +121,13 @@ SIGNATURES = {
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
     "nnc_kmeans_fit_reference_f32": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nnc_compress_layer_workspace_bytes": (c_size, [c_i64, c_i32]),
+    "nnc_compress_layer_host_bytes": (c_size, []),
+    "nnc_compress_layer_f32": (c_int, [c_void_p, c_i64, ctypes.POINTER(LayerParams), c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p, c_size,
+                                       ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(LayerResult), c_void_p]),
+    "nnc_host_linspace_f32": (c_int, [c_f32, c_f32, c_i32, c_void_p]),
+    "nnc_host_cdf": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nnc_host_density_init": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_kmeanspp_trials": (c_i32, [c_i32]),
     "nnc_kmeanspp_workspace_bytes": (c_size, [c_i64, c_i32]),
     "nnc_kmeanspp_seed_f32": (c_int, [c_void_p, c_i64, c_f32, c_i32, c_i64, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),

@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 DIAG = os.environ.get("NNC_DIAG", "0") not in ("", "0")   # diagnostics build (phase traces, ablated kernels): tools/ only
 LIB = os.path.join(CSRC, "libnnc_hip_diag.so" if DIAG else "libnnc_hip.so")
-SOURCES = [os.path.join(CSRC, "nnc_hip.hip"), os.path.join(CSRC, "nnc_sort.hip"), os.path.join(CSRC, "nnc_pp.hip"), os.path.join(CSRC, "nnc_codec.hip")]
+SOURCES = [os.path.join(CSRC, "nnc_hip.hip"), os.path.join(CSRC, "nnc_sort.hip"), os.path.join(CSRC, "nnc_pp.hip"), os.path.join(CSRC, "nnc_codec.hip"), os.path.join(CSRC, "nnc_layer.hip")]
 EXTRA_LIBS: list = []
 
 

@@ -661,4 +661,5 @@ class DeviceKMeans:
         # samples tied at the selection cut (the fits may part ways there), events with more than one empty cluster
         model.reloc_tie_ = int(st.reloc_ties)
         model.n_reloc_multi_ = int(st.reloc_multi)
+        model.arith_ = "fixed"
         return model, vals

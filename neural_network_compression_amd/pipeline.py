@@ -124,12 +124,72 @@ def initial_centroids(x: torch.Tensor, bits: int, mode: str, cdfs=None, group=No
     raise Exception(" error mode not found")
 
 
+# ------------------------------------------------------------------ the whole layer as one call into the library
+_LAYER_TLS = threading.local()
+
+
+def _layer_host_block():
+    """This host thread's pinned block for nnc_compress_layer_f32 (status slots, scalars, the K-sized read) and its ticket
+    counter, which lives as long as the block."""
+    blk = getattr(_LAYER_TLS, "blk", None)
+    if blk is None:
+        import ctypes
+
+        from . import _native as nat
+
+        nb = int(nat.load().nnc_compress_layer_host_bytes())
+        blk = _LAYER_TLS.blk = (torch.zeros(nb, dtype=torch.uint8, pin_memory=True), ctypes.c_uint64(0), nat.LayerResult())
+    return blk
+
+
+def _compress_layer_native(x: torch.Tensor, q, std_smooth: bool, bits: int, mode: str, want_values: bool):
+    """nnc_compress_layer_f32 (include/nnc.h) on a whole tensor of one GPU, modes linear / density.  Returns a LayerResult, or
+    (mask, sigma, threshold, nzeroed) of the pruned tensor when the library leaves the fit to the step-by-step path."""
+    import ctypes
+
+    from . import _native as nat
+
+    L = nat.load()
+    n = x.numel()
+    k = 2 ** bits + (1 if mode == "density" else 0)
+    dev = x.device
+    ws_bytes = int(L.nnc_compress_layer_workspace_bytes(n, k))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev) if q is not None else None
+    labels = torch.empty(n, dtype=torch.uint8 if k <= 256 else torch.int16, device=dev)
+    values = torch.empty(n, dtype=torch.float32, device=dev) if want_values else None
+    pinned, ticket, res = _layer_host_block()
+    lp = nat.LayerParams(q=float(np.float32(q)) if q is not None else 0.0, prune=1 if q is not None else 0, std_smooth=1 if std_smooth else 0,
+                         bits=int(bits), mode=1 if mode == "density" else 0, want_values=1 if want_values else 0)
+    nat.check(L.nnc_compress_layer_f32(x.data_ptr(), n, ctypes.byref(lp), ops._ptr(mask), labels.data_ptr(), ops._ptr(values), ws.data_ptr(), ws_bytes,
+                                       pinned.data_ptr(), pinned.numel(), ctypes.byref(ticket), ctypes.byref(res), ops._stream(x)))
+    mask_b = mask   # (uint8, like ops.prune_)
+    sigma = thr = nz = None
+    if q is not None:
+        sigma, thr, nz = float(res.sigma), float(res.threshold), int(res.n_zeroed)
+    if res.status != 0:
+        return mask_b, sigma, thr, nz
+    centers = np.frombuffer(res.centers, dtype=np.float32, count=k).copy()
+    counts = np.frombuffer(res.counts, dtype=np.int64, count=k).copy()
+    lengths = np.frombuffer(res.code_lengths, dtype=np.uint8, count=k).copy()
+    model = _kmeans.QuantizedModel(centers, labels, int(res.n_iter), int(res.n_relocations), {1: "tol", 2: "max_iter", 3: "strict"}.get(int(res.stop), "?"))
+    model.counts_host_ = counts
+    model.n_reloc_windowed_ = int(res.n_reloc_windowed)
+    model.reloc_tie_ = int(res.reloc_ties)
+    model.n_reloc_multi_ = int(res.reloc_multi)
+    model.arith_ = "reference" if res.arith == 1 else "fixed"
+    top = int(lengths.max()) if k else 0
+    lhist = np.bincount(lengths, minlength=top + 1).astype(np.int64)
+    return LayerResult(mask_b, nz, sigma, thr, values, model, counts, lengths, lhist, int(res.total_bits))
+
+
 def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int = 4, mode: str = "linear",
                    with_cdf: bool | None = None, group=None, huffman: bool = True,
-                   want_values: bool = True, comm=None, arith: str = "auto") -> LayerResult:
+                   want_values: bool = True, comm=None, arith: str = "auto", native: bool = True) -> LayerResult:
     """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part.
     ``group``: torch.distributed group of one rank per GPU when `x` is a shard; ``comm`` (sharding.RcclComm over the same
-    ranks) moves the per-iteration exchange of the fit into the C library.  ``arith``: kmeans.fit_vector."""
+    ranks) moves the per-iteration exchange of the fit into the C library.  ``arith``: kmeans.fit_vector.  ``native``: let
+    the library run the whole layer as one call where it can (same results; ``False``: the step-by-step path)."""
     x = x.reshape(-1)
     ops._require_cuda(x, "x", torch.float32)
     n_total = n_min = x.numel()
@@ -142,6 +202,16 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         n_total, n_min = int(sizes.sum()), int(sizes.min())
     mask = nz = sigma = thr = None
     early = None
+    pre = None
+    if (native and group is None and arith == "auto" and mode in ("linear", "density") and huffman and with_cdf in (None, mode == "density")
+            and 1 <= bits <= 10 and n_total >= (2 ** bits) + 1 and x.is_contiguous()):
+        # the whole layer as one call into the library (nnc_compress_layer_f32); it hands the fit back when that needs the
+        # step-by-step path (short tensor with the density init, full-pass relocation, strict-convergence check)
+        out = _compress_layer_native(x, q, std_smooth, bits, mode, want_values)
+        if isinstance(out, LayerResult):
+            return out
+        pre = out          # (mask, sigma, threshold, nzeroed): the tensor is pruned already
+        q = None
     if q is not None:
         mask, stats, nzt = prune_sharded_(x, q, std_smooth, group, n_total)
         if group is None:
@@ -195,6 +265,8 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         else:
             sf = stats.reshape(-1)[:2].cpu().numpy()
             sigma, thr, nz = float(sf[0]), float(sf[1]), int(nzt.item())
+    if pre is not None:
+        mask, sigma, thr, nz = pre
     return LayerResult(mask, nz, sigma, thr, values, model, counts, lengths, lhist, total)
 
 

@@ -181,3 +181,52 @@ def test_cdf_from_counts_is_scipys():
         want, got = reference(steps, counts), _cdf_from_counts(steps, counts)
         assert want[0].dtype == got[0].dtype and want[1].dtype == got[1].dtype
         assert np.array_equal(want[0], got[0]) and np.array_equal(want[1], got[1]), t
+
+
+def test_host_arithmetic_of_the_layer_call_is_numpys(lib):
+    """nnc_host_linspace_f32 / nnc_host_cdf / nnc_host_density_init (the K-sized host steps inside nnc_compress_layer_f32) against
+    NumPy, scipy and the oracle's restatement of utility.py:206-226, 374-392, bit for bit."""
+    from scipy.interpolate import interp1d
+
+    rs = np.random.RandomState(11)
+    fp, dp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)
+    for t in range(300):
+        a = np.float32(rs.randn() * 10.0 ** rs.randint(-6, 3))
+        b = np.float32(a + np.float32(abs(rs.randn()) * 10.0 ** rs.randint(-7, 3)))
+        for num in (1, 2, 4, 16, 32, 33, 257, 300, 1024):
+            want = np.linspace(a, b, num=num)
+            assert want.dtype == np.float32
+            got = np.empty(num, dtype=np.float32)
+            assert lib.nnc_host_linspace_f32(float(a), float(b), num, got.ctypes.data) == 0
+            assert np.array_equal(want, got), (t, num)
+    # degenerate spans: equal ends, reversed ends
+    for a, b in ((0.5, 0.5), (1.0, -1.0), (0.0, 1e-45), (-3e-39, 3e-39)):
+        want = np.linspace(np.float32(a), np.float32(b), num=32)
+        got = np.empty(32, dtype=np.float32)
+        assert lib.nnc_host_linspace_f32(float(np.float32(a)), float(np.float32(b)), 32, got.ctypes.data) == 0
+        assert np.array_equal(want, got), (a, b)
+    for t in range(300):
+        a, b = np.float32(rs.randn() * 0.1 - 0.2), np.float32(rs.rand() * 0.5 + 0.01)
+        steps = np.linspace(a, a + b, num=32)
+        counts = rs.randint(0, 10 ** rs.randint(1, 8), size=31).astype(np.int64)
+        if t % 4 == 0:
+            counts[rs.randint(0, 31, size=12)] = 0
+        counts[-1] += 1
+        # the reference's sequence of calls (utility.py:374-392)
+        x = steps[:-1]
+        tot_counter = np.array([int(c) for c in counts]) / (np.sum([int(c) for c in counts]))
+        cdf = []
+        for i in range(len(tot_counter)):
+            cdf.append(tot_counter[i] if i == 0 else tot_counter[i] + cdf[i - 1])
+        cdf = np.array(cdf)
+        cdf = cdf / cdf[-1]
+        xnew = np.linspace(min(x), max(x), 300)
+        ynew = interp1d(x, cdf, "linear")(xnew)
+        gx, gy = np.empty(300, dtype=np.float32), np.empty(300, dtype=np.float64)
+        assert lib.nnc_host_cdf(steps.ctypes.data, counts.ctypes.data, gx.ctypes.data, gy.ctypes.data) == 0
+        assert np.array_equal(xnew, gx) and np.array_equal(ynew, gy), t
+        for bits in (2, 4, 5, 8):
+            want = orc.init_space(np.zeros(4, dtype=np.float32), bits, "density", (xnew, ynew))
+            got = np.empty(2 ** bits + 1, dtype=np.float32)
+            assert lib.nnc_host_density_init(gx.ctypes.data, gy.ctypes.data, bits, got.ctypes.data) == 0
+            assert np.array_equal(np.asarray(want, dtype=np.float32), got) and np.asarray(want).dtype == np.float32, (t, bits)

@@ -119,3 +119,28 @@ def test_layers_side_by_side_equal_one_after_the_other():
     f2 = pipeline.compress_layers([torch.from_numpy(w.copy()).cuda() for w in host[:4]], workers=4, q=1.0, bits=3, mode="forgy")
     for a, b in zip(f1, f2):
         assert np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_)
+
+
+@pytest.mark.parametrize("mode", ["linear", "density"])
+def test_layer_as_one_library_call_equals_the_step_by_step_path(mode):
+    """nnc_compress_layer_f32 (prune -> statistics -> sort -> weight distribution -> init -> fit -> labels -> histogram -> Huffman
+    lengths in one host call, the K-sized NumPy / scipy arithmetic restated in C) against the same steps issued one by one."""
+    from neural_network_compression_amd import pipeline
+
+    shapes = [(768,), (3072,), (4097,), (600, 20), (768, 768), (300_001,), (64, 3, 3, 3), (5000,)]
+    for i, s in enumerate(shapes):
+        for bits, q in ((4, 1.0), (2, 0.5), (8, 1.0), (5, None)):
+            w = synth.weights(s, 8800 + i)
+            if w.size < 2 ** bits + 1:
+                continue
+            a = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=q, bits=bits, mode=mode, native=False)
+            b = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=q, bits=bits, mode=mode, native=True)
+            key = (s, bits, q)
+            if q is not None:
+                assert a.nzeroed == b.nzeroed and a.sigma == b.sigma and a.threshold == b.threshold and torch.equal(a.mask.view(torch.uint8), b.mask.view(torch.uint8)), key
+            assert a.model.n_iter_ == b.model.n_iter_ and a.model.stop_reason_ == b.model.stop_reason_, key
+            assert np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_), key
+            assert np.array_equal(a.model.labels_, b.model.labels_) and torch.equal(a.values, b.values), key
+            assert a.model.n_relocations_ == b.model.n_relocations_ and a.model.arith_ == b.model.arith_, key
+            assert np.array_equal(a.counts, b.counts) and np.array_equal(a.code_lengths, b.code_lengths), key
+            assert np.array_equal(a.length_hist, b.length_hist) and a.total_bits == b.total_bits, key
