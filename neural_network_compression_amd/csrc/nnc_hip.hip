@@ -3019,6 +3019,28 @@ extern "C" int nnc_kmeans_status_publish(void *ws, void *host_mapped, uint64_t t
     return NNC_OK;
 }
 
+// A few bytes (scalars, a K-sized block) from device memory straight into host memory the device can write, then a ticket
+// behind them: what a copy command plus a stream synchronisation would do, for the price of one small launch and a spin.
+__global__ __launch_bounds__(256) void k_publish_bytes(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ dst_host, int nwords,
+                                                       unsigned long long *host_ticket, unsigned long long ticket)
+{
+    for (int i = threadIdx.x; i < nwords; i += 256) dst_host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
+}
+
+// (shared with nnc_layer.hip) nbytes a multiple of 8, both pointers 8-byte aligned
+int nnc_publish_bytes_(const void *src_dev, void *dst_host_mapped, int nbytes, void *host_ticket, uint64_t ticket, void *stream)
+{
+    if (!src_dev || !dst_host_mapped || !host_ticket || nbytes < 0 || (nbytes & 7) || ((reinterpret_cast<uintptr_t>(src_dev) | reinterpret_cast<uintptr_t>(dst_host_mapped)) & 7))
+        return fail(NNC_EINVAL, "publish: bad argument");
+    hipLaunchKernelGGL(k_publish_bytes, dim3(1), dim3(256), 0, S(stream), reinterpret_cast<const unsigned long long *>(src_dev),
+                       reinterpret_cast<unsigned long long *>(dst_host_mapped), nbytes / 8, reinterpret_cast<unsigned long long *>(host_ticket), (unsigned long long)ticket);
+    LAUNCHCHK("k_publish_bytes");
+    return NNC_OK;
+}
+
 __global__ void k_set_done(KmWs *ws, int code) { ws->st.done = code; }
 
 extern "C" int nnc_kmeans_set_done(void *ws, int32_t done_code, void *stream)
@@ -4301,6 +4323,11 @@ extern "C" int nnc_debug_spec_stage(const float *x_sorted, void *ws, const nnc_k
 // (status.paused == 2: the proof of a windowed selection failed; paused == 1: windows not applicable, the strict-convergence
 // check is due, or the scratch is too small).  The caller handles that and calls again.
 // --------------------------------------------------------------------------------------
+static int km_wait_ticket(volatile unsigned long long *word, unsigned long long ticket, hipStream_t stream);
+int nnc_wait_ticket_(void *host_ticket, uint64_t ticket, void *stream) // (shared with nnc_layer.hip)
+{
+    return km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(host_ticket), (unsigned long long)ticket, S(stream));
+}
 static int km_wait_ticket(volatile unsigned long long *word, unsigned long long ticket, hipStream_t stream)
 {
     unsigned long long spins = 0;

@@ -17,6 +17,8 @@
 #include "nnc.h"
 
 int nnc_set_error_(int code, const char *msg); // in nnc_hip.hip
+int nnc_publish_bytes_(const void *src_dev, void *dst_host_mapped, int nbytes, void *host_ticket, uint64_t ticket, void *stream);
+int nnc_wait_ticket_(void *host_ticket, uint64_t ticket, void *stream);
 
 // --------------------------------------------------------------------------------------
 // host arithmetic, NumPy's way
@@ -160,8 +162,8 @@ static LayerLayout layer_layout(int64_t n, int32_t k)
     L.init = take((size_t)NNC_KMAX * 4);
     L.prefix = take(std::max<size_t>(L.prefix_bytes, 16));
     L.reloc = take(std::max<size_t>(L.reloc_bytes, 16));
-    L.back = take((size_t)k * 12);
-    L.small_out = take(64 + 256);
+    L.back = take((size_t)k * 12);     // index histogram (k int64) | centres (k float32) ...
+    L.small_out = take(64 + 256);      // ... and right behind it the one-launch fit's result block: one read covers both
     L.total = o + 256;
     return L;
 }
@@ -197,9 +199,22 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     unsigned char *wb = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws_dev) + 255) & ~(uintptr_t)255);
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_pinned);
-    // host block: [0, 512) the fit's two status slots; [512, 1024) scalars; [1024, ...) the K-sized read at the end
-    float *h_f = reinterpret_cast<float *>(hb + 512);       // out6 | prune stats[2]
-    int64_t *h_i = reinterpret_cast<int64_t *>(hb + 576);   // signs[2] | nzeroed | 33 ranks
+    // host block: [0, 504) the fit's two status slots; 504 the ticket of this call's own reads; [512, 576) a mirror of the
+    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed); [576, 896) ranks; [896, 1024) the 32 steps
+    // on their way out; [1024, ...) the K-sized read at the end.  A read = one small launch that copies into the block and
+    // writes a ticket behind the bytes; the thread spins on the ticket (nnc_kmeans_status_publish's way).
+    const float *h_f = reinterpret_cast<const float *>(hb + 512);                // out6
+    const int64_t *h_signs = reinterpret_cast<const int64_t *>(hb + 512 + 32);   // #negative, #zero
+    const float *h_prune = reinterpret_cast<const float *>(hb + 512 + 48);       // sigma, threshold
+    const int64_t *h_nz = reinterpret_cast<const int64_t *>(hb + 512 + 56);
+    int64_t *h_ranks = reinterpret_cast<int64_t *>(hb + 576);
+    void *h_ticket = hb + 504;
+    auto read_back = [&](const void *src, void *dst, int nbytes) -> int {
+        const uint64_t t = ++(*ticket_io);
+        int rc = nnc_publish_bytes_(src, dst, nbytes, h_ticket, t, stream);
+        if (rc) return rc;
+        return nnc_wait_ticket_(h_ticket, t, stream);
+    };
     std::memset(res, 0, sizeof(*res));
     res->k = k;
     res->label_bytes = k <= 256 ? 1 : 2;
@@ -211,16 +226,14 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
     // ---- prune_weigth (utility.py:131-169): in place
     if (lp->prune) {
         LCHK(nnc_prune_f32(x, n, lp->q, lp->std_smooth ? 1 : 0, mask_out, pstats, nzeroed, wb + L.prune_ws, L.prune_ws_bytes, stream));
-        LHIP(hipMemcpyAsync(h_f + 6, pstats, 8, hipMemcpyDeviceToHost, s));
-        LHIP(hipMemcpyAsync(h_i + 2, nzeroed, 8, hipMemcpyDeviceToHost, s));
     }
     const bool short_tensor = n <= NNC_REF_NMAX && k <= NNC_REF_KMAX;
     // (not taken here: short tensors with the density init, tensors too short for the sorted form.  The tensor is pruned
     // already; the caller's own path goes on from there, see status)
     if ((short_tensor && lp->mode != NNC_INIT_LINEAR) || (!short_tensor && n < 512)) {
         if (lp->prune) {
-            LHIP(hipStreamSynchronize(s));
-            res->sigma = h_f[6]; res->threshold = h_f[7]; res->n_zeroed = h_i[2];
+            LCHK(read_back(out6, hb + 512, 64));
+            res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0];
         }
         res->status = NNC_LAYER_HOST;
         return NNC_OK;
@@ -238,28 +251,25 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         // ---- a short tensor: min / max -> linear init -> the whole fit in one launch, in the reference's own arithmetic
         float *mm = out6;
         LCHK(nnc_minmax_f32(x, n, 0, mm, signs, wb + L.stats_ws, L.stats_ws_bytes, stream));
-        LHIP(hipMemcpyAsync(h_f, mm, 8, hipMemcpyDeviceToHost, s));
-        LHIP(hipStreamSynchronize(s));
+        LCHK(read_back(out6, hb + 512, 64));
         LCHK(nnc_host_linspace_f32(h_f[0], h_f[1], k, space));
         std::memcpy(h_space, space, (size_t)k * 4);
         LHIP(hipMemcpyAsync(init_d, h_space, (size_t)k * 4, hipMemcpyHostToDevice, s));
         void *result_d = wb + L.small_out;
         LCHK(nnc_kmeans_fit_reference_f32(x, (int32_t)n, init_d, k, 300, 1e-4f, reinterpret_cast<uint8_t *>(labels_out), lp->want_values ? values_out : nullptr,
                                           centers_d, counts_d, result_d, stream));
-        LHIP(hipMemcpyAsync(h_counts, back, (size_t)k * 12, hipMemcpyDeviceToHost, s));
-        int32_t *h_res = reinterpret_cast<int32_t *>(hb + 1024 + (size_t)k * 12 + ((8 - ((size_t)k * 12) % 8) % 8));
-        LHIP(hipMemcpyAsync(h_res, result_d, 32, hipMemcpyDeviceToHost, s));
-        LHIP(hipStreamSynchronize(s));
+        // (the 32-byte result block sits right behind the K-sized block on the device, see layer_layout: one read)
+        const int back_bytes = (int)al((size_t)k * 12) + 32;
+        LCHK(read_back(back, hb + 1024, back_bytes));
+        const int32_t *h_res = reinterpret_cast<const int32_t *>(hb + 1024 + al((size_t)k * 12));
         res->n_iter = h_res[0]; res->stop = h_res[1]; res->n_relocations = h_res[2]; res->reloc_ties = h_res[3]; res->reloc_multi = h_res[4];
         res->arith = NNC_ARITH_REFERENCE;
     } else {
         // ---- statistics (one host read), sorted copy
         LCHK(nnc_layer_stats_f32(x, n, out6, signs, wb + L.stats_ws, L.stats_ws_bytes, stream));
-        LHIP(hipMemcpyAsync(h_f, out6, 24, hipMemcpyDeviceToHost, s));
-        LHIP(hipMemcpyAsync(h_i, signs, 16, hipMemcpyDeviceToHost, s));
-        LHIP(hipStreamSynchronize(s));
+        LCHK(read_back(out6, hb + 512, 64));
         const float mean = h_f[0], var = h_f[1], xmin = h_f[2], xmax = h_f[3], min_nz = h_f[4], max_nz = h_f[5];
-        const int64_t n_neg = h_i[0], n_zero = h_i[1];
+        const int64_t n_neg = h_signs[0], n_zero = h_signs[1];
         float *xs = reinterpret_cast<float *>(wb + L.sorted);
         if (4 * n_zero >= n) LCHK(nnc_sort_pruned_f32(x, n, n_neg, n_zero, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
         else LCHK(nnc_sort_f32(x, n, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
@@ -286,10 +296,9 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
             std::memcpy(h_steps, steps, 128);
             LHIP(hipMemcpyAsync(steps_d, h_steps, 128, hipMemcpyHostToDevice, s));
             LCHK(nnc_rank_sorted_f32(xs, n, steps_d, 32, ranks_d, stream));
-            LHIP(hipMemcpyAsync(h_i + 3, ranks_d, 32 * 8, hipMemcpyDeviceToHost, s));
-            LHIP(hipStreamSynchronize(s));
+            LCHK(read_back(ranks_d, h_ranks, 32 * 8));
             int64_t counts31[31];
-            for (int b = 0; b < 31; b++) counts31[b] = h_i[3 + b + 1] - h_i[3 + b];
+            for (int b = 0; b < 31; b++) counts31[b] = h_ranks[b + 1] - h_ranks[b];
             for (int b = 0; b < 31; b++)
                 if (steps[b] <= 0.0f && 0.0f < steps[b + 1]) { counts31[b] -= n_zero; break; } // the zeros sit in that bin of the full vector
             float xnew[300];
@@ -310,7 +319,7 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         int32_t nwin = 0;
         LCHK(nnc_kmeans_fit(xs, wb + L.km_ws, &p, 8, 1, L.reloc_bytes ? wb + L.reloc : nullptr, L.reloc_bytes, hb, ticket_io, &st, &nwin, stream));
         if (!st.done) { // full-pass relocation / strict-convergence check: the caller's own path (from the pruned tensor)
-            if (lp->prune) { res->sigma = h_f[6]; res->threshold = h_f[7]; res->n_zeroed = h_i[2]; }
+            if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
             res->status = NNC_LAYER_HOST;
             return NNC_OK;
         }
@@ -318,13 +327,12 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         LCHK(nnc_kmeans_get_centers(wb + L.km_ws, 0, 0, centers_d, stream));
         LCHK(nnc_kmeans_assign(x, wb + L.km_ws, &p, 0, labels_out, res->label_bytes, lp->want_values ? values_out : nullptr, nullptr, nullptr, stream));
         LCHK(nnc_kmeans_label_counts(xs, wb + L.km_ws, &p, 0, counts_d, stream));
-        LHIP(hipMemcpyAsync(h_counts, back, (size_t)k * 12, hipMemcpyDeviceToHost, s));
-        LHIP(hipStreamSynchronize(s));
+        LCHK(read_back(back, hb + 1024, (int)al((size_t)k * 12)));
         res->n_iter = st.iter; res->stop = st.done; res->n_relocations = nwin; res->n_reloc_windowed = nwin;
         res->reloc_ties = st.reloc_ties; res->reloc_multi = st.reloc_multi;
         res->arith = NNC_ARITH_FIXED;
     }
-    if (lp->prune) { res->sigma = h_f[6]; res->threshold = h_f[7]; res->n_zeroed = h_i[2]; }
+    if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
     std::memcpy(res->counts, h_counts, (size_t)k * 8);
     std::memcpy(res->centers, h_centers, (size_t)k * 4);
     int64_t hist[72]; // (nnc_huffman_lengths fills up to 65 entries: symbols per code length)
