@@ -163,7 +163,6 @@ DIAG_SIGNATURES = {
     "nnc_debug_set_trace": (c_int, [c_void_p]),
     "nnc_debug_clock": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
-    "nnc_debug_spec_stage": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_int, c_void_p]),
 }
 
 _lib = None

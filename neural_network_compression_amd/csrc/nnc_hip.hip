@@ -4269,7 +4269,7 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
 // `wmax`; the look-in of a batch rides on the last launch (the resumed finalize).
 #define KM_SPEC_WMAX 256
 static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans_params *p, void *scratch_dev, void *stream,
-                                void *host_mapped, uint64_t ticket, int stages = 31)
+                                void *host_mapped, uint64_t ticket)
 {
     const int32_t wmax = KM_SPEC_WMAX;
     const int64_t cap = reloc_cap(p->k, wmax);
@@ -4288,32 +4288,21 @@ static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         g_reloc_dist_attr[current_device()].store(1, std::memory_order_release);
     }
-    if (stages & 1)
     hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n, w, 0, (long long)cap, win, meta, hist0, (int)wmax);
     LAUNCHCHK("k_reloc_windows");
-    if (stages & 2)
     hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, (nnc_kmeans_status *)nullptr,
                        (unsigned long long *)nullptr, 0ull, 1, 0, 1);
     LAUNCHCHK("k_cells");
     // (sized for windows of 64, the common case: the kernel strides over whatever there is)
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (2 * (int64_t)64 * (p->k + 1) + KM_THREADS - 1) / KM_THREADS));
-    if (stages & 4)
     hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, win, meta, cand_x, cand_d, (long long)cap,
                        reinterpret_cast<const KmWs *>(w), hist0, 1);
     LAUNCHCHK("k_reloc_dist");
-    if (stages & 8)
     hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), w, cand_x, cand_d, win, meta, 0, keys, 1, hist0, 1);
     LAUNCHCHK("k_reloc_select");
-    if (!(stages & 16)) return NNC_OK;
     return km_launch_finalize(w, p, FIN_FROM_PARTIALS, 2, stream, host_mapped, ticket);
 }
 
-#ifdef NNC_DIAG
-extern "C" int nnc_debug_spec_stage(const float *x_sorted, void *ws, const nnc_kmeans_params *p, void *scratch_dev, int stages, void *stream)
-{
-    return km_launch_spec_reloc(x_sorted, reinterpret_cast<KmWs *>(ws), p, scratch_dev, stream, nullptr, 0, stages);
-}
-#endif
 
 // --------------------------------------------------------------------------------------
 // The Lloyd loop of one fit on one GPU as ONE call: batches of iterations, the look-ins (the status block arrives in pinned

@@ -297,7 +297,7 @@ def _worker_stream(dev) -> torch.cuda.Stream:
     return st[dev]
 
 
-def compress_layers(layers, workers: int = 4, **kw):
+def compress_layers(layers, workers: int = 8, **kw):
     """compress_layer for every tensor of ``layers`` (device float32 tensors, each pruned in place when ``q`` is given),
     ``workers`` of them side by side on streams of their own; the results come back in the order of ``layers`` and are the ones
     the calls would give one after the other.  Modes that draw from NumPy's global generator (forgy) run one after the other,
