@@ -288,7 +288,11 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         if (lp->mode == NNC_INIT_LINEAR) {
             LCHK(nnc_host_linspace_f32(xmin, xmax, k, space));
         } else {
-            if (!std::isfinite(min_nz)) return nnc_set_error_(NNC_EINVAL, "zero-size array to reduction operation minimum which has no identity");
+            if (!std::isfinite(min_nz)) { // no non-zero weight: the reference's numpy call raises; so does the caller's own path
+                if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
+                res->status = NNC_LAYER_HOST;
+                return NNC_OK;
+            }
             float steps[32];
             LCHK(nnc_host_linspace_f32(min_nz, max_nz, 32, steps));
             float *steps_d = reinterpret_cast<float *>(wb + L.steps);

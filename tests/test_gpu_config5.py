@@ -144,3 +144,38 @@ def test_layer_as_one_library_call_equals_the_step_by_step_path(mode):
             assert a.model.n_relocations_ == b.model.n_relocations_ and a.model.arith_ == b.model.arith_, key
             assert np.array_equal(a.counts, b.counts) and np.array_equal(a.code_lengths, b.code_lengths), key
             assert np.array_equal(a.length_hist, b.length_hist) and a.total_bits == b.total_bits, key
+
+
+def test_layer_call_edge_cases():
+    """The one-call layer against the step-by-step path where the data are awkward: everything pruned, constant tensors,
+    a 4-byte-aligned view, lengths that are no multiple of 4."""
+    from neural_network_compression_amd import pipeline
+
+    def both(w, **kw):
+        out = []
+        for native in (False, True):
+            t = torch.from_numpy(np.ascontiguousarray(w).copy()).cuda()
+            out.append(pipeline.compress_layer(t, native=native, **kw))
+        return out
+
+    def same(a, b):
+        assert (a.model is None) == (b.model is None)
+        assert a.nzeroed == b.nzeroed and a.sigma == b.sigma and a.threshold == b.threshold
+        assert np.array_equal(a.mask.cpu().numpy().astype(bool), b.mask.cpu().numpy().astype(bool))
+        assert a.model.n_iter_ == b.model.n_iter_ and np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_, equal_nan=True)
+        assert np.array_equal(a.model.labels_, b.model.labels_) and torch.equal(a.values, b.values)
+        assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
+
+    w = synth.weights((20_001,), 31)
+    same(*both(w, q=100.0, bits=4, mode="linear"))                       # every weight pruned: all zeros
+    for native in (False, True):                                          # ... and no non-zero weight for the distribution
+        with pytest.raises(ValueError, match="zero-size array"):
+            pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=100.0, bits=4, mode="density", native=native)
+    same(*both(np.full(9_999, 0.25, dtype=np.float32), q=0.5, bits=3, mode="linear"))     # constant: sigma 0, nothing pruned
+    same(*both(np.full(3_000, -0.5, dtype=np.float32), q=0.5, bits=2, mode="linear"))     # ... on the short-tensor path
+    same(*both(synth.weights((70_003,), 32), q=1.0, bits=6, mode="density"))
+    # a view that is only 4-byte aligned
+    base = torch.from_numpy(synth.weights((50_004,), 33)).cuda()
+    r1 = pipeline.compress_layer(base.clone()[3:], q=1.0, bits=4, mode="density", native=False)
+    r2 = pipeline.compress_layer(base.clone()[3:], q=1.0, bits=4, mode="density", native=True)
+    same(r1, r2)
