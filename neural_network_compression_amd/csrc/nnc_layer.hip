@@ -134,8 +134,26 @@ extern "C" int nnc_host_density_init(const float *xnew300, const double *cdf300,
 // --------------------------------------------------------------------------------------
 static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// A second stream (and two events) per host thread: the mean / variance passes of a long tensor run beside its sort.
+struct SideStream { int dev = -1; hipStream_t stream = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static int side_stream(SideStream **out)
+{
+    static thread_local SideStream side;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nnc_set_error_(NNC_EHIP, "hipGetDevice failed");
+    if (side.dev != dev) {
+        if (side.stream) { (void)hipStreamDestroy(side.stream); (void)hipEventDestroy(side.fork); (void)hipEventDestroy(side.join); side = SideStream(); }
+        if (hipStreamCreateWithFlags(&side.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&side.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&side.join, hipEventDisableTiming) != hipSuccess)
+            return nnc_set_error_(NNC_EHIP, "could not create the second stream");
+        side.dev = dev;
+    }
+    *out = &side;
+    return NNC_OK;
+}
+
 struct LayerLayout {
-    size_t prune_ws, stats_out, stats_ws, sorted, sort_ws, steps, ranks, km_ws, init, prefix, reloc, back, small_out, total;
+    size_t prune_ws, stats_out, stats_ws, sorted, sort_ws, steps, km_ws, init, prefix, reloc, back, small_out, total;
     size_t prune_ws_bytes, stats_ws_bytes, sort_ws_bytes, km_ws_bytes, prefix_bytes, reloc_bytes;
 };
 
@@ -152,12 +170,11 @@ static LayerLayout layer_layout(int64_t n, int32_t k)
     L.prefix_bytes = nnc_kmeans_prefix_bytes(n);
     L.reloc_bytes = n >= 512 ? nnc_kmeans_reloc_scratch_bytes(k, 256) : 0;
     L.prune_ws = take(std::max<size_t>(L.prune_ws_bytes, 16));
-    L.stats_out = take(6 * 4 + 2 * 8 + 2 * 4 + 8 + 64); // out6 | signs[2] | prune stats[2] | nzeroed
+    L.stats_out = take(512); // out6 | signs[2] | prune stats[2] | nzeroed | ranks[33] (one read covers them)
     L.stats_ws = take(std::max<size_t>(L.stats_ws_bytes, 16));
     L.sorted = take((size_t)n * 4 + 16);
     L.sort_ws = take(std::max<size_t>(L.sort_ws_bytes, 16));
     L.steps = take(32 * 4);
-    L.ranks = take(33 * 8);
     L.km_ws = take(L.km_ws_bytes);
     L.init = take((size_t)NNC_KMAX * 4);
     L.prefix = take(std::max<size_t>(L.prefix_bytes, 16));
@@ -200,7 +217,7 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
     unsigned char *wb = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws_dev) + 255) & ~(uintptr_t)255);
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_pinned);
     // host block: [0, 504) the fit's two status slots; 504 the ticket of this call's own reads; [512, 576) a mirror of the
-    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed); [576, 896) ranks; [896, 1024) the 32 steps
+    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed), [576, 840) the ranks behind it; [896, 1024) the 32 steps
     // on their way out; [1024, ...) the K-sized read at the end.  A read = one small launch that copies into the block and
     // writes a ticket behind the bytes; the thread spins on the ticket (nnc_kmeans_status_publish's way).
     const float *h_f = reinterpret_cast<const float *>(hb + 512);                // out6
@@ -265,16 +282,50 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         res->n_iter = h_res[0]; res->stop = h_res[1]; res->n_relocations = h_res[2]; res->reloc_ties = h_res[3]; res->reloc_multi = h_res[4];
         res->arith = NNC_ARITH_REFERENCE;
     } else {
-        // ---- statistics (one host read), sorted copy
-        LCHK(nnc_layer_stats_f32(x, n, out6, signs, wb + L.stats_ws, L.stats_ws_bytes, stream));
+        // ---- min / max and the sign counts first (the sort needs the counts on the host); mean and variance -- two passes and
+        // two single-wave folds, 90 us of mostly latency -- then run on a second stream beside the sort
+        const int64_t nch = (n + 8191) / 8192; // NumPy's summation chunk
+        float *c1 = reinterpret_cast<float *>(wb + L.stats_ws), *c2 = c1 + nch;
+        unsigned char *mm_ws = wb + L.stats_ws + al(2 * (size_t)nch * sizeof(float));
+        LCHK(nnc_minmax_signs_f32(x, n, out6 + 2, signs, mm_ws, nnc_minmax_workspace_bytes(n), stream));
         LCHK(read_back(out6, hb + 512, 64));
-        const float mean = h_f[0], var = h_f[1], xmin = h_f[2], xmax = h_f[3], min_nz = h_f[4], max_nz = h_f[5];
+        const float xmin = h_f[2], xmax = h_f[3], min_nz = h_f[4], max_nz = h_f[5];
         const int64_t n_neg = h_signs[0], n_zero = h_signs[1];
+        SideStream *side = nullptr;
+        LCHK(side_stream(&side));
+        LHIP(hipEventRecord(side->fork, s));
+        LHIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+        LCHK(nnc_chunk_sums_f32(x, n, 0, nullptr, c1, side->stream));
+        LCHK(nnc_fold_f32(c1, nch, n, NNC_FOLD_MEAN, nullptr, out6, side->stream));           // [0] = mean
+        LCHK(nnc_chunk_sums_f32(x, n, 1, out6, c2, side->stream));
+        LCHK(nnc_fold_f32(c2, nch, n, NNC_FOLD_MEAN, nullptr, out6 + 1, side->stream));       // [1] = variance
+        LHIP(hipEventRecord(side->join, side->stream));
         float *xs = reinterpret_cast<float *>(wb + L.sorted);
         if (4 * n_zero >= n) LCHK(nnc_sort_pruned_f32(x, n, n_neg, n_zero, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
         else LCHK(nnc_sort_f32(x, n, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
-        // ---- k-means set-up that does not depend on the initial centres: parameters, prefix sums (enqueued before the host
-        // turns to the weight distribution, so that the device has work meanwhile)
+        const bool with_prefix = (reinterpret_cast<uintptr_t>(xs) & 15) == 0;
+        int64_t *ranks_d = reinterpret_cast<int64_t *>(wb + L.stats_out + 64);
+        h_ranks = reinterpret_cast<int64_t *>(hb + 512 + 64);
+        float steps[32];
+        if (lp->mode == NNC_INIT_DENSITY) {
+            if (!std::isfinite(min_nz)) { // no non-zero weight: the reference's numpy call raises; so does the caller's own path
+                LHIP(hipStreamWaitEvent(s, side->join, 0));
+                LHIP(hipStreamSynchronize(s));
+                if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
+                res->status = NNC_LAYER_HOST;
+                return NNC_OK;
+            }
+            LCHK(nnc_host_linspace_f32(min_nz, max_nz, 32, steps));
+            float *steps_d = reinterpret_cast<float *>(wb + L.steps);
+            std::memcpy(h_steps, steps, 128);
+            LHIP(hipMemcpyAsync(steps_d, h_steps, 128, hipMemcpyHostToDevice, s));
+            LCHK(nnc_rank_sorted_f32(xs, n, steps_d, 32, ranks_d, stream));
+        }
+        // ---- the second read: mean, variance (and the ranks)
+        LHIP(hipStreamWaitEvent(s, side->join, 0));
+        LCHK(read_back(out6, hb + 512, 64 + 33 * 8));
+        const float mean = h_f[0], var = h_f[1];
+        // ---- k-means parameters (KMeans.fit's tolerance and centring, _kmeans.py:279-287, 1479-1484; the fixed-point rule)
         nnc_kmeans_params p;
         std::memset(&p, 0, sizeof(p));
         const volatile float tol = var * 1e-4f;                 // np.mean(np.var(X, axis=0)) * tol, float32
@@ -283,24 +334,10 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         p.fix_shift = nnc_fix_shift(std::max(std::fabs((float)lo), std::fabs((float)hi)), n);
         p.grid_log2 = 0; p.replicas_log2 = -1; p.flags = 0;
         p.x_mean = mean; p.tol = tol; p.lo = lo; p.hi = hi;
-        const bool with_prefix = (reinterpret_cast<uintptr_t>(xs) & 15) == 0;
         // ---- initial centroids (utility.py:206-226)
         if (lp->mode == NNC_INIT_LINEAR) {
             LCHK(nnc_host_linspace_f32(xmin, xmax, k, space));
         } else {
-            if (!std::isfinite(min_nz)) { // no non-zero weight: the reference's numpy call raises; so does the caller's own path
-                if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
-                res->status = NNC_LAYER_HOST;
-                return NNC_OK;
-            }
-            float steps[32];
-            LCHK(nnc_host_linspace_f32(min_nz, max_nz, 32, steps));
-            float *steps_d = reinterpret_cast<float *>(wb + L.steps);
-            int64_t *ranks_d = reinterpret_cast<int64_t *>(wb + L.ranks);
-            std::memcpy(h_steps, steps, 128);
-            LHIP(hipMemcpyAsync(steps_d, h_steps, 128, hipMemcpyHostToDevice, s));
-            LCHK(nnc_rank_sorted_f32(xs, n, steps_d, 32, ranks_d, stream));
-            LCHK(read_back(ranks_d, h_ranks, 32 * 8));
             int64_t counts31[31];
             for (int b = 0; b < 31; b++) counts31[b] = h_ranks[b + 1] - h_ranks[b];
             for (int b = 0; b < 31; b++)
