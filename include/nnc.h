@@ -90,6 +90,13 @@ size_t nnc_prune_workspace_bytes(int64_t n);
 int nnc_prune_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev,
                   int64_t *nzeroed_dev, void *ws, size_t ws_bytes, void *stream);
 
+/* nnc_prune_f32 and, in the same pass over the vector, what nnc_minmax_signs_f32 would report of the PRUNED tensor
+ * (minmax4_dev = {min, max, min over the non-zeros, max over the non-zeros}, signs_dev = {#negative, #zero}): the statistics the
+ * sort and the k-means set-up need next, without reading the tensor again.  ws: nnc_prune_stats_workspace_bytes(n). */
+size_t nnc_prune_stats_workspace_bytes(int64_t n);
+int nnc_prune_stats_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev, int64_t *nzeroed_dev,
+                        float *minmax4_dev, int64_t *signs_dev, void *ws, size_t ws_bytes, void *stream);
+
 /* Same elementwise pass with the threshold already on the device (sharded pruning: the
  * ranks all-gather their chunk sums, fold, and each thresholds its own shard). */
 int nnc_threshold_mask_f32(float *x, int64_t n, const float *thr_dev, uint8_t *mask, int64_t *nzeroed_dev,

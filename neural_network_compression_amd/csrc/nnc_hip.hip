@@ -630,6 +630,112 @@ extern "C" int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, i
     return minmax_impl(x, n, 0, out_dev, nullptr, signs_dev, ws, ws_bytes, stream);
 }
 
+// The threshold pass AND the min / max / sign statistics of what it leaves behind, in one pass over the vector: the pruned
+// values are in registers anyway, and the statistics pass that the sort and the k-means set-up need next (nnc_minmax_signs_f32)
+// would read them again.  Same mask, same zeroing, same count as k_threshold; same partials as k_minmax.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_threshold_stats(float *__restrict__ x, int64_t n, const float *__restrict__ thr_dev,
+                                                         uint8_t *__restrict__ mask, unsigned long long *__restrict__ nzeroed,
+                                                         MinMaxPartial *__restrict__ part)
+{
+    const float thr = *thr_dev;
+    unsigned cnt = 0, neg = 0, zer = 0;
+    float mn = INFINITY, mx = -INFINITY, mn_nz = INFINITY, mx_nz = -INFINITY;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    int64_t done = 0;
+#define TS1(v) do { const float v_ = (v); neg += (v_ < 0.0f); const bool z_ = (v_ == 0.0f); zer += z_; \
+        if (!z_) { mn_nz = fminf(mn_nz, v_); mx_nz = fmaxf(mx_nz, v_); } mn = fminf(mn, v_); mx = fmaxf(mx, v_); } while (0)
+    if (VEC) {
+        const int64_t nvec = n >> 2;
+        float4 *x4 = reinterpret_cast<float4 *>(x);
+        uchar4 *m4 = reinterpret_cast<uchar4 *>(mask);
+        for (int64_t v = tid; v < nvec; v += nthreads) {
+            float4 a = x4[v];
+            uchar4 m;
+            m.x = fabsf(a.x) < thr; m.y = fabsf(a.y) < thr; m.z = fabsf(a.z) < thr; m.w = fabsf(a.w) < thr;
+            cnt += m.x + m.y + m.z + m.w;
+            a.x = m.x ? 0.0f : a.x; a.y = m.y ? 0.0f : a.y; a.z = m.z ? 0.0f : a.z; a.w = m.w ? 0.0f : a.w;
+            x4[v] = a;
+            m4[v] = m;
+            TS1(a.x); TS1(a.y); TS1(a.z); TS1(a.w);
+        }
+        done = nvec << 2;
+    }
+    for (int64_t i = done + tid; i < n; i += nthreads) {
+        float a = x[i];
+        const uint8_t m = fabsf(a) < thr;
+        cnt += m;
+        if (m) { a = 0.0f; x[i] = 0.0f; }
+        mask[i] = m;
+        TS1(a);
+    }
+#undef TS1
+    unsigned long long negl = neg, zerl = zer, cntl = cnt;
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off));
+        mx = fmaxf(mx, __shfl_down(mx, off));
+        mn_nz = fminf(mn_nz, __shfl_down(mn_nz, off));
+        mx_nz = fmaxf(mx_nz, __shfl_down(mx_nz, off));
+        negl += __shfl_down(negl, off);
+        zerl += __shfl_down(zerl, off);
+        cntl += __shfl_down(cntl, off);
+    }
+    __shared__ MinMaxPartial sh[4];
+    __shared__ unsigned long long shc[4];
+    if ((threadIdx.x & 63) == 0) {
+        MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = 0; q.neg = negl; q.zer = zerl; q.mn_nz = mn_nz; q.mx_nz = mx_nz;
+        sh[threadIdx.x >> 6] = q; shc[threadIdx.x >> 6] = cntl;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        MinMaxPartial p = sh[0];
+        unsigned long long tot = shc[0];
+        for (int w = 1; w < 4; w++) {
+            p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.neg += sh[w].neg; p.zer += sh[w].zer;
+            p.mn_nz = fminf(p.mn_nz, sh[w].mn_nz); p.mx_nz = fmaxf(p.mx_nz, sh[w].mx_nz);
+            tot += shc[w];
+        }
+        part[blockIdx.x] = p;
+        if (nzeroed && tot) atomicAdd(nzeroed, tot);
+    }
+}
+
+extern "C" size_t nnc_prune_stats_workspace_bytes(int64_t n) { return ((nnc_prune_workspace_bytes(n) + 255) & ~(size_t)255) + nnc_minmax_workspace_bytes(n); }
+
+extern "C" int nnc_prune_stats_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev, int64_t *nzeroed_dev,
+                                   float *minmax4_dev, int64_t *signs_dev, void *ws, size_t ws_bytes, void *stream)
+{
+    if (n <= 0 || !x || !mask || !stats_dev || !minmax4_dev || !signs_dev || !ws) return fail(NNC_EINVAL, "nnc_prune_stats_f32: bad argument (n must be > 0)");
+    if (ws_bytes < nnc_prune_stats_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_prune_stats_f32: workspace too small");
+    if (std_smooth) {
+        float *wsf = reinterpret_cast<float *>(ws);
+        float *scal = wsf;          // [0] mean, [1] q
+        float *chunks = wsf + 16;
+        const int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
+        int rc;
+        hipLaunchKernelGGL(k_set_f32, dim3(1), dim3(1), 0, S(stream), q, scal + 1);
+        LAUNCHCHK("k_set_f32");
+        if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, chunks, stream))) return rc;
+        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_MEAN, nullptr, scal, stream))) return rc;
+        if ((rc = nnc_chunk_sums_f32(x, n, 1, scal, chunks, stream))) return rc;
+        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_STD, scal + 1, stats_dev, stream))) return rc; // stats = {sigma, sigma * q}
+    } else {
+        hipLaunchKernelGGL(k_set_thr, dim3(1), dim3(1), 0, S(stream), q, stats_dev);
+        LAUNCHCHK("k_set_thr");
+    }
+    if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
+    MinMaxPartial *part = reinterpret_cast<MinMaxPartial *>(reinterpret_cast<unsigned char *>(ws) + ((nnc_prune_workspace_bytes(n) + 255) & ~(size_t)255));
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
+    const int grid = std::min(stream_grid((n + 3) / 4, 256, 4), cu_count() * 8);
+    if (vec) NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold_stats<true>), dim3(grid), dim3(256), 0, S(stream), x, n, stats_dev + 1, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev), part);
+    else NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold_stats<false>), dim3(grid), dim3(256), 0, S(stream), x, n, stats_dev + 1, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev), part);
+    LAUNCHCHK("k_threshold_stats");
+    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, minmax4_dev, (long long *)nullptr, reinterpret_cast<long long *>(signs_dev));
+    LAUNCHCHK("k_minmax_final");
+    return NNC_OK;
+}
+
 // Everything LayerStats wants of one (whole, single-GPU) vector, enqueued by one call: NumPy-exact mean and variance
 // (the two chunk-sum passes and their folds) and the min / max / sign pass.
 extern "C" size_t nnc_layer_stats_workspace_bytes(int64_t n)

@@ -162,7 +162,7 @@ static LayerLayout layer_layout(int64_t n, int32_t k)
     LayerLayout L;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
-    L.prune_ws_bytes = nnc_prune_workspace_bytes(n);
+    L.prune_ws_bytes = nnc_prune_stats_workspace_bytes(n);
     L.stats_ws_bytes = std::max(nnc_layer_stats_workspace_bytes(n), nnc_minmax_workspace_bytes(n));
     // the pruned sort is taken when at least a quarter of the weights are zero: its workspace is largest at exactly a quarter
     L.sort_ws_bytes = std::max(nnc_sort_workspace_bytes(n), nnc_sort_pruned_workspace_bytes(n, 0, (n + 3) / 4));
@@ -241,9 +241,12 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
     float *pstats = reinterpret_cast<float *>(wb + L.stats_out + 48);
     int64_t *nzeroed = reinterpret_cast<int64_t *>(wb + L.stats_out + 56);
     // ---- prune_weigth (utility.py:131-169): in place
-    if (lp->prune) {
-        LCHK(nnc_prune_f32(x, n, lp->q, lp->std_smooth ? 1 : 0, mask_out, pstats, nzeroed, wb + L.prune_ws, L.prune_ws_bytes, stream));
-    }
+    // ... and, in the same pass, min / max (over all and over the non-zero weights) and the sign counts of what is left:
+    // out6[2..5], signs.  Without pruning: the statistics pass on its own.
+    if (lp->prune)
+        LCHK(nnc_prune_stats_f32(x, n, lp->q, lp->std_smooth ? 1 : 0, mask_out, pstats, nzeroed, out6 + 2, signs, wb + L.prune_ws, L.prune_ws_bytes, stream));
+    else
+        LCHK(nnc_minmax_signs_f32(x, n, out6 + 2, signs, wb + L.stats_ws, L.stats_ws_bytes, stream));
     const bool short_tensor = n <= NNC_REF_NMAX && k <= NNC_REF_KMAX;
     // (not taken here: short tensors with the density init, tensors too short for the sorted form.  The tensor is pruned
     // already; the caller's own path goes on from there, see status)
@@ -266,10 +269,8 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
 
     if (short_tensor) {
         // ---- a short tensor: min / max -> linear init -> the whole fit in one launch, in the reference's own arithmetic
-        float *mm = out6;
-        LCHK(nnc_minmax_f32(x, n, 0, mm, signs, wb + L.stats_ws, L.stats_ws_bytes, stream));
         LCHK(read_back(out6, hb + 512, 64));
-        LCHK(nnc_host_linspace_f32(h_f[0], h_f[1], k, space));
+        LCHK(nnc_host_linspace_f32(h_f[2], h_f[3], k, space));
         std::memcpy(h_space, space, (size_t)k * 4);
         LHIP(hipMemcpyAsync(init_d, h_space, (size_t)k * 4, hipMemcpyHostToDevice, s));
         void *result_d = wb + L.small_out;
@@ -282,12 +283,10 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         res->n_iter = h_res[0]; res->stop = h_res[1]; res->n_relocations = h_res[2]; res->reloc_ties = h_res[3]; res->reloc_multi = h_res[4];
         res->arith = NNC_ARITH_REFERENCE;
     } else {
-        // ---- min / max and the sign counts first (the sort needs the counts on the host); mean and variance -- two passes and
-        // two single-wave folds, 90 us of mostly latency -- then run on a second stream beside the sort
+        // ---- min / max and the sign counts are read first (the sort needs the counts on the host); mean and variance -- two passes
+        // and two single-wave folds, 90 us of mostly latency -- then run on a second stream beside the sort
         const int64_t nch = (n + 8191) / 8192; // NumPy's summation chunk
         float *c1 = reinterpret_cast<float *>(wb + L.stats_ws), *c2 = c1 + nch;
-        unsigned char *mm_ws = wb + L.stats_ws + al(2 * (size_t)nch * sizeof(float));
-        LCHK(nnc_minmax_signs_f32(x, n, out6 + 2, signs, mm_ws, nnc_minmax_workspace_bytes(n), stream));
         LCHK(read_back(out6, hb + 512, 64));
         const float xmin = h_f[2], xmax = h_f[3], min_nz = h_f[4], max_nz = h_f[5];
         const int64_t n_neg = h_signs[0], n_zero = h_signs[1];

@@ -133,6 +133,26 @@ def prune_(x: torch.Tensor, q: float, std_smooth: bool = True):
     return mask.view(x.shape), stats, nz
 
 
+def prune_stats_(x: torch.Tensor, q: float, std_smooth: bool = True):
+    """prune_ and, from the same pass, minmax_signs of the pruned tensor: (mask, stats, nzeroed, float32[4] = {min, max, min
+    over the non-zeros, max over the non-zeros}, int64[2] = {#negative, #zero})."""
+    _require_cuda(x, "x", torch.float32)
+    if x.numel() == 0:
+        raise ValueError("zero-size array to reduction operation minimum which has no identity")
+    L = nat.load()
+    n = x.numel()
+    mask = torch.empty(n, dtype=torch.uint8, device=x.device)
+    stats = torch.empty(2, dtype=torch.float32, device=x.device) if std_smooth else torch.zeros(2, dtype=torch.float32, device=x.device)
+    nz = torch.empty(1, dtype=torch.int64, device=x.device)
+    mm = torch.empty(4, dtype=torch.float32, device=x.device)
+    signs = torch.empty(2, dtype=torch.int64, device=x.device)
+    ws_bytes = L.nnc_prune_stats_workspace_bytes(n)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    nat.check(L.nnc_prune_stats_f32(_ptr(x), n, float(np.float32(q)), 1 if std_smooth else 0, _ptr(mask), _ptr(stats), _ptr(nz), _ptr(mm), _ptr(signs),
+                                    _ptr(ws), ws_bytes, _stream(x)))
+    return mask.view(x.shape), stats, nz, mm, signs
+
+
 def threshold_mask_(x: torch.Tensor, thr_dev: torch.Tensor):
     """In place threshold pass with the float32 threshold already on the device."""
     _require_cuda(x, "x", torch.float32)

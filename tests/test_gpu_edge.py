@@ -253,3 +253,28 @@ def test_layer_statistics_in_one_call(km_mod, n):
     else:
         assert np.isinf(st.min_nonzero) and np.isinf(st.max_nonzero)
     assert st.n_negative == int((x < 0).sum()) and st.n_zero == int((x == 0).sum())
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 1000, 8191, 8192, 8193, 70_001, 1_000_003])
+def test_prune_with_statistics_in_one_pass(km_mod, n):
+    """nnc_prune_stats_f32 = nnc_prune_f32 followed by nnc_minmax_signs_f32 of the pruned tensor, from one pass."""
+    _, ops = km_mod
+    w = synth.weights((n,), 4400 + n % 97)
+    if n > 10:
+        w[::7] = 0.0
+        w[3] = -0.0
+    for q, smooth in ((1.0, True), (0.0, True), (0.05, False), (100.0, True)):
+        a = torch.from_numpy(w.copy()).cuda()
+        b = torch.from_numpy(w.copy()).cuda()[0:]          # (aligned)
+        m1, s1, z1 = ops.prune_(a, q, smooth)
+        mm1, sg1 = ops.minmax_signs(a)
+        m2, s2, z2, mm2, sg2 = ops.prune_stats_(b, q, smooth)
+        assert torch.equal(a, b) and torch.equal(m1, m2) and torch.equal(s1, s2) and int(z1.item()) == int(z2.item()), (n, q)
+        assert torch.equal(mm1, mm2) and torch.equal(sg1, sg2), (n, q, mm1.tolist(), mm2.tolist(), sg1.tolist(), sg2.tolist())
+    if n > 8:   # a 4-byte-aligned view
+        base = torch.from_numpy(np.concatenate([np.zeros(1, np.float32), w])).cuda()
+        c, d = base.clone()[1:], base.clone()[1:]
+        m1, s1, z1 = ops.prune_(c, 1.0, True)
+        mm1, sg1 = ops.minmax_signs(c)
+        m2, s2, z2, mm2, sg2 = ops.prune_stats_(d, 1.0, True)
+        assert torch.equal(c, d) and torch.equal(m1, m2) and torch.equal(mm1, mm2) and torch.equal(sg1, sg2)
