@@ -2252,6 +2252,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             if (tid == 0) {
                 for (int j = 0; j < k; j++) tot_empty += (cnt_o[j] == 0); // rare path, exact count
                 ws->st.paused = 1; ws->st.n_empty = tot_empty;
+                if (lazy) ws->tab[cur].n_ovf = 0; // the cell table of this (current) table is rebuilt on demand: start its side list empty
             }
             return false;
         }
@@ -2648,23 +2649,22 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
 // cell table, so they leave it stale; the kernels that look samples up -- labels, relocation candidates -- ask for it).
 __global__ void k_cells_prepare(KmWs *__restrict__ ws, int which) { ws->tab[ws->cur ^ (which & 1)].n_ovf = 0; }
 
-__global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc_kmeans_status *host_st,
-                                                      unsigned long long *host_ticket, unsigned long long ticket,
-                                                      int force = 0, int which = 0, int spec = 0)
+__device__ __forceinline__ void km_cells_body(KmWs *__restrict__ ws, nnc_kmeans_status *host_st, unsigned long long *host_ticket,
+                                              unsigned long long ticket, int force, int which, int spec, const int bid)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX];
     if (spec && !ws->spec_go) return; // (enqueued in case of an empty-cluster event: there is none to settle)
     // the last launch of a batch may carry the host's look-in (nnc_kmeans_iterate_publish): the state is final once
     // k_finalize is through, so the status block and the ticket go out here, without a launch of their own
-    if (host_st && blockIdx.x == 0 && threadIdx.x == 0) {
+    if (host_st && bid == 0 && threadIdx.x == 0) {
         *host_st = ws->st;
         __threadfence_system();
         *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
     }
     if (!force && !ws->cells_pending) return;
     const int G = 1 << ws->glog2;
-    const int g = blockIdx.x * KM_THREADS + threadIdx.x;
-    if ((int)(blockIdx.x * KM_THREADS) >= G) return;
+    const int g = bid * KM_THREADS + threadIdx.x;
+    if ((int)(bid * KM_THREADS) >= G) return;
     KmTab *tab = &ws->tab[ws->cur ^ (which & 1)];
     const int ku = force ? tab->ku : ws->ku_cur;
     if (!force) {
@@ -2709,6 +2709,13 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     }
     if (g >= G) return;
     tab->cell[g] = km_cell_entry(g, G, ku, gcell, hcell, &tab->n_ovf, tab->ovf);
+}
+
+__global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc_kmeans_status *host_st,
+                                                      unsigned long long *host_ticket, unsigned long long ticket,
+                                                      int force = 0, int which = 0, int spec = 0)
+{
+    km_cells_body(ws, host_st, host_ticket, ticket, force, which, spec, (int)blockIdx.x);
 }
 
 static bool km_fused(const nnc_kmeans_params *p)
@@ -3847,21 +3854,25 @@ __device__ __forceinline__ void block_scan2(long long &a0, long long &a1, long l
 // for the host's strict-convergence check, window (the host's rule, nnc_kmeans_reloc_window) within the scratch -- and says so
 // in ws->spec_go for the launches behind it (k_cells, k_reloc_dist, k_reloc_select, the resumed finalize), which do nothing
 // otherwise.
-__global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws,
-                                                              int W, long long cap, KmWin *__restrict__ win, int *__restrict__ meta,
-                                                              unsigned *__restrict__ hist0 = nullptr, int spec_wmax = 0)
+// (the decision of a chain enqueued "in case": every thread of every workgroup that asks gets the same answer)
+__device__ __forceinline__ bool km_spec_decide(const KmWs *__restrict__ ws, long long n, int spec_wmax, int *W_out)
+{
+    const int done = ws->st.done, paused = ws->st.paused, it = ws->st.iter, same = ws->st.same_counts, ne = ws->st.n_empty;
+    long long w = KM_RELOC_WMIN;
+    while (w < ne) w *= 2;
+    if (W_out) *W_out = (int)w;
+    return !done && paused == 1 && !(it >= 1 && same) && ne >= 1 && w <= spec_wmax && 2 * w <= n;
+}
+
+__device__ __forceinline__ void km_reloc_windows_body(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int W, long long cap,
+                                                      KmWin *__restrict__ win, int *__restrict__ meta, unsigned *__restrict__ hist0, int spec_wmax)
 {
     if (spec_wmax > 0) {
-        const int done = ws->st.done, paused = ws->st.paused, it = ws->st.iter, same = ws->st.same_counts, ne = ws->st.n_empty;
-        long long w = KM_RELOC_WMIN;
-        while (w < ne) w *= 2;
-        const bool go = !done && paused == 1 && !(it >= 1 && same) && ne >= 1 && w <= spec_wmax && 2 * w <= n;
-        if (threadIdx.x == 0) {
-            ws->spec_go = go ? 1 : 0;
-            if (go) ws->tab[ws->cur].n_ovf = 0; // (what k_cells_prepare does for the table build behind this launch)
-        }
+        const bool go = km_spec_decide(ws, n, spec_wmax, &W);
+        // (the overflow list of the table k_cells rebuilds beside or behind this workgroup was emptied by the finalize step
+        // that paused: km_finalize_body)
+        if (threadIdx.x == 0) ws->spec_go = go ? 1 : 0;
         if (!go) return;
-        W = (int)w;
     }
     if (hist0) for (int i = threadIdx.x; i < 4096; i += KM_THREADS) hist0[i] = 0u; // k_reloc_dist adds to it
     __shared__ long long bnd[2 * KM_THREADS + 2];
@@ -3921,6 +3932,27 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__res
         const long long total = ((nwin - 1) & 1) ? l1 : l0;
         const int over = total > cap ? 1 : 0;
         meta[0] = over ? 0 : (int)total; meta[1] = nwin; meta[2] = bad | over; meta[3] = W;
+    }
+}
+
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_windows(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws,
+                                                              int W, long long cap, KmWin *__restrict__ win, int *__restrict__ meta,
+                                                              unsigned *__restrict__ hist0 = nullptr, int spec_wmax = 0)
+{
+    if (spec_wmax > 0 && threadIdx.x == 0 && km_spec_decide(ws, n, spec_wmax, nullptr)) ws->tab[ws->cur].n_ovf = 0; // (launched on its own: k_cells follows)
+    km_reloc_windows_body(xs, n, ws, W, cap, win, meta, hist0, spec_wmax);
+}
+
+// Head of the relocation chain enqueued "in case": the window table (last workgroup) and the cell table of the current centres
+// (the others) side by side -- neither needs the other, both read the zones.
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_head(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, long long cap,
+                                                           KmWin *__restrict__ win, int *__restrict__ meta, unsigned *__restrict__ hist0, int spec_wmax)
+{
+    if (blockIdx.x == gridDim.x - 1) {
+        km_reloc_windows_body(xs, n, ws, 0, cap, win, meta, hist0, spec_wmax);
+    } else {
+        if (!km_spec_decide(ws, n, spec_wmax, nullptr)) return;
+        km_cells_body(ws, nullptr, nullptr, 0ull, 1, 0, 0, (int)blockIdx.x);
     }
 }
 
@@ -4394,11 +4426,9 @@ static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         g_reloc_dist_attr[current_device()].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n, w, 0, (long long)cap, win, meta, hist0, (int)wmax);
-    LAUNCHCHK("k_reloc_windows");
-    hipLaunchKernelGGL(k_cells, dim3(KM_GMAX / KM_THREADS), dim3(KM_THREADS), 0, S(stream), w, (nnc_kmeans_status *)nullptr,
-                       (unsigned long long *)nullptr, 0ull, 1, 0, 1);
-    LAUNCHCHK("k_cells");
+    hipLaunchKernelGGL(k_reloc_head, dim3(KM_GMAX / KM_THREADS + 1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n, w, (long long)cap, win, meta,
+                       hist0, (int)wmax);
+    LAUNCHCHK("k_reloc_head");
     // (sized for windows of 64, the common case: the kernel strides over whatever there is)
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (2 * (int64_t)64 * (p->k + 1) + KM_THREADS - 1) / KM_THREADS));
     hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, win, meta, cand_x, cand_d, (long long)cap,
