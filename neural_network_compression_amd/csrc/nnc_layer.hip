@@ -364,15 +364,11 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
             return NNC_OK;
         }
         // ---- labels + decoded values from the original order, index histogram, centres: one host read
-        // (the index histogram comes from one more rank-boundary pass over the sorted copy: beside the labelling pass, on the
-        // second stream)
-        LHIP(hipEventRecord(side->fork, s));
-        LHIP(hipStreamWaitEvent(side->stream, side->fork, 0));
-        LCHK(nnc_kmeans_label_counts(xs, wb + L.km_ws, &p, 0, counts_d, side->stream));
-        LHIP(hipEventRecord(side->join, side->stream));
+        // (one after the other: beside the labelling pass the index histogram's launches take bandwidth from it -- measured: the
+        // labelling pass 43.6 -> 45.5 us for 15 us saved)
         LCHK(nnc_kmeans_get_centers(wb + L.km_ws, 0, 0, centers_d, stream));
         LCHK(nnc_kmeans_assign(x, wb + L.km_ws, &p, 0, labels_out, res->label_bytes, lp->want_values ? values_out : nullptr, nullptr, nullptr, stream));
-        LHIP(hipStreamWaitEvent(s, side->join, 0));
+        LCHK(nnc_kmeans_label_counts(xs, wb + L.km_ws, &p, 0, counts_d, stream));
         LCHK(read_back(back, hb + 1024, (int)al((size_t)k * 12)));
         res->n_iter = st.iter; res->stop = st.done; res->n_relocations = nwin; res->n_reloc_windowed = nwin;
         res->reloc_ties = st.reloc_ties; res->reloc_multi = st.reloc_multi;
