@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--dump-durations", action="store_true", help="stderr: the per-launch durations (us) of the iteration kernels of the last step")
     ap.add_argument("--no-streaming-leg", action="store_true", help="skip the separate timing of the streaming Lloyd pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--step-by-step", action="store_true", help="drive the layer's steps from Python (pipeline.compress_layer(native=False)) instead of "
+                                                                "the one-call form (nnc_compress_layer_f32): for comparison")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path with all ranks on one GPU: --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -162,7 +164,7 @@ def main():
     def step():
         x = w0.clone()  # prune works in place; the copy is device-to-device, inside the timed region
         return pipeline.compress_layer(x, q=args.q, bits=args.bits, mode=args.mode, group=group, comm=comm,
-                                       huffman=True, want_values=True)
+                                       huffman=True, want_values=True, native=not args.step_by_step)
 
     def barrier():
         if group is not None:
