@@ -259,7 +259,6 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         return NNC_OK;
     }
     float space[NNC_KMAX];
-    float *init_d = reinterpret_cast<float *>(wb + L.init);
     unsigned char *back = wb + L.back;
     int64_t *counts_d = reinterpret_cast<int64_t *>(back);
     float *centers_d = reinterpret_cast<float *>(back + (size_t)k * 8);
@@ -271,10 +270,9 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         // ---- a short tensor: min / max -> linear init -> the whole fit in one launch, in the reference's own arithmetic
         LCHK(read_back(out6, hb + 512, 64));
         LCHK(nnc_host_linspace_f32(h_f[2], h_f[3], k, space));
-        std::memcpy(h_space, space, (size_t)k * 4);
-        LHIP(hipMemcpyAsync(init_d, h_space, (size_t)k * 4, hipMemcpyHostToDevice, s));
+        std::memcpy(h_space, space, (size_t)k * 4); // (the kernel reads the k floats straight from the pinned block: no copy command)
         void *result_d = wb + L.small_out;
-        LCHK(nnc_kmeans_fit_reference_f32(x, (int32_t)n, init_d, k, 300, 1e-4f, reinterpret_cast<uint8_t *>(labels_out), lp->want_values ? values_out : nullptr,
+        LCHK(nnc_kmeans_fit_reference_f32(x, (int32_t)n, h_space, k, 300, 1e-4f, reinterpret_cast<uint8_t *>(labels_out), lp->want_values ? values_out : nullptr,
                                           centers_d, counts_d, result_d, stream));
         // (the 32-byte result block sits right behind the K-sized block on the device, see layer_layout: one read)
         const int back_bytes = (int)al((size_t)k * 12) + 32;
@@ -315,10 +313,8 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
                 return NNC_OK;
             }
             LCHK(nnc_host_linspace_f32(min_nz, max_nz, 32, steps));
-            float *steps_d = reinterpret_cast<float *>(wb + L.steps);
-            std::memcpy(h_steps, steps, 128);
-            LHIP(hipMemcpyAsync(steps_d, h_steps, 128, hipMemcpyHostToDevice, s));
-            LCHK(nnc_rank_sorted_f32(xs, n, steps_d, 32, ranks_d, stream));
+            std::memcpy(h_steps, steps, 128); // (read by the kernel straight from the pinned block)
+            LCHK(nnc_rank_sorted_f32(xs, n, h_steps, 32, ranks_d, stream));
         }
         // ---- the second read: mean, variance (and the ranks)
         LHIP(hipStreamWaitEvent(s, side->join, 0));
@@ -347,8 +343,7 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
             LCHK(nnc_host_density_init(xnew, cdf, lp->bits, space));
         }
         std::memcpy(h_space, space, (size_t)k * 4);
-        LHIP(hipMemcpyAsync(init_d, h_space, (size_t)k * 4, hipMemcpyHostToDevice, s));
-        LCHK(nnc_kmeans_init(wb + L.km_ws, L.km_ws_bytes, &p, init_d, stream));
+        LCHK(nnc_kmeans_init(wb + L.km_ws, L.km_ws_bytes, &p, h_space, stream));
         if (with_prefix) {
             LCHK(nnc_kmeans_prefix_build(xs, &p, reinterpret_cast<int64_t *>(wb + L.prefix), stream));
             p.prefix_dev = reinterpret_cast<int64_t *>(wb + L.prefix);
