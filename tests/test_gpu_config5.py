@@ -161,7 +161,9 @@ def test_layer_call_edge_cases():
     def same(a, b):
         assert (a.model is None) == (b.model is None)
         assert a.nzeroed == b.nzeroed and a.sigma == b.sigma and a.threshold == b.threshold
-        assert np.array_equal(a.mask.cpu().numpy().astype(bool), b.mask.cpu().numpy().astype(bool))
+        assert (a.mask is None) == (b.mask is None)
+        if a.mask is not None:
+            assert np.array_equal(a.mask.cpu().numpy().astype(bool), b.mask.cpu().numpy().astype(bool))
         assert a.model.n_iter_ == b.model.n_iter_ and np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_, equal_nan=True)
         assert np.array_equal(a.model.labels_, b.model.labels_) and torch.equal(a.values, b.values)
         assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
@@ -174,6 +176,9 @@ def test_layer_call_edge_cases():
     same(*both(np.full(9_999, 0.25, dtype=np.float32), q=0.5, bits=3, mode="linear"))     # constant: sigma 0, nothing pruned
     same(*both(np.full(3_000, -0.5, dtype=np.float32), q=0.5, bits=2, mode="linear"))     # ... on the short-tensor path
     same(*both(synth.weights((70_003,), 32), q=1.0, bits=6, mode="density"))
+    same(*both(synth.weights((120_000,), 34), q=1.0, bits=10, mode="density"))            # 1025 centroids: the largest K, 16-bit indices
+    same(*both(synth.weights((120_000,), 35), q=None, bits=10, mode="linear"))
+    same(*both(synth.weights((600,), 36), q=1.0, bits=8, mode="density"))                 # more centroids than the short-tensor form takes
     # a view that is only 4-byte aligned
     base = torch.from_numpy(synth.weights((50_004,), 33)).cuda()
     r1 = pipeline.compress_layer(base.clone()[3:], q=1.0, bits=4, mode="density", native=False)
