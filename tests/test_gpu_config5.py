@@ -50,6 +50,20 @@ def test_gpt2_small_layer_list_full_pipeline():
           f"{iters} Lloyd iterations; Huffman {bits / total:.3f} bits / weight")
     assert dt < 1.0   # (an order of magnitude of slack over the measured time; the CPU path takes minutes)
 
+    # ---- all 122 tensors side by side (eight host threads, a stream each): the same results, tensor by tensor
+    clones = [t.clone() for _, t in tensors]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    par = pipeline.compress_layers(clones, workers=8, q=1.0, bits=4, mode="linear", huffman=True, want_values=True)
+    torch.cuda.synchronize()
+    dtp = time.perf_counter() - t0
+    print(f"   side by side (8 workers): {dtp * 1e3:.1f} ms = {total / dtp / 1e9:.2f} G weights/s")
+    for (name, _), a, b in zip(tensors, res.values(), par):
+        assert a.model.n_iter_ == b.model.n_iter_ and np.array_equal(a.model.cluster_centers_, b.model.cluster_centers_), name
+        assert torch.equal(a.model.labels_compact_, b.model.labels_compact_) and torch.equal(a.values, b.values), name
+        assert torch.equal(a.mask, b.mask) and a.nzeroed == b.nzeroed and a.sigma == b.sigma, name
+        assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits, name
+
     # ---- every tensor: what the path guarantees at any size
     for (name, t), r in zip(tensors, res.values()):
         n = t.numel()
