@@ -153,7 +153,7 @@ static int side_stream(SideStream **out)
 }
 
 struct LayerLayout {
-    size_t prune_ws, stats_out, stats_ws, sorted, sort_ws, steps, km_ws, init, prefix, reloc, back, small_out, total;
+    size_t prune_ws, stats_out, stats_ws, sorted, sort_ws, km_ws, prefix, reloc, back, small_out, total;
     size_t prune_ws_bytes, stats_ws_bytes, sort_ws_bytes, km_ws_bytes, prefix_bytes, reloc_bytes;
 };
 
@@ -174,9 +174,7 @@ static LayerLayout layer_layout(int64_t n, int32_t k)
     L.stats_ws = take(std::max<size_t>(L.stats_ws_bytes, 16));
     L.sorted = take((size_t)n * 4 + 16);
     L.sort_ws = take(std::max<size_t>(L.sort_ws_bytes, 16));
-    L.steps = take(32 * 4);
     L.km_ws = take(L.km_ws_bytes);
-    L.init = take((size_t)NNC_KMAX * 4);
     L.prefix = take(std::max<size_t>(L.prefix_bytes, 16));
     L.reloc = take(std::max<size_t>(L.reloc_bytes, 16));
     L.back = take((size_t)k * 12);     // index histogram (k int64) | centres (k float32) ...
@@ -192,7 +190,7 @@ extern "C" size_t nnc_compress_layer_workspace_bytes(int64_t n, int32_t k)
 }
 
 // host block: [0, 512) the fit's two status slots | [512, 1024) scalars, ranks, the 32 steps | [1024, 16384) the K-sized read at
-// the end | [16384, 24576) the initial centres on their way to the device
+// the end | [16384, 24576) the initial centres (the kernels read them from here)
 extern "C" size_t nnc_compress_layer_host_bytes(void) { return 24576; }
 
 #define LCHK(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
@@ -217,8 +215,8 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
     unsigned char *wb = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws_dev) + 255) & ~(uintptr_t)255);
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_pinned);
     // host block: [0, 504) the fit's two status slots; 504 the ticket of this call's own reads; [512, 576) a mirror of the
-    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed), [576, 840) the ranks behind it; [896, 1024) the 32 steps
-    // on their way out; [1024, ...) the K-sized read at the end.  A read = one small launch that copies into the block and
+    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed), [576, 840) the ranks behind it; [896, 1024) the 32 histogram
+    // steps (read from here by the rank kernel); [1024, ...) the K-sized read at the end.  A read = one small launch that copies into the block and
     // writes a ticket behind the bytes; the thread spins on the ticket (nnc_kmeans_status_publish's way).
     const float *h_f = reinterpret_cast<const float *>(hb + 512);                // out6
     const int64_t *h_signs = reinterpret_cast<const int64_t *>(hb + 512 + 32);   // #negative, #zero
