@@ -124,6 +124,16 @@ int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, in
 int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
                          void *stream);
 
+/* The pruned sort when the bounds of the surviving weights are known (vmin <= x <= -thr or thr <= x <= vmax for every non-zero
+ * x, as after nnc_prune_f32 with threshold thr; vmin / vmax from nnc_minmax_signs_f32): their order-preserving integer images
+ * relative to the two ends fit in nnc_sort_pruned_bounded_bits(...) bits (0: the form does not apply -- no threshold, or more
+ * than 27 bits), and a hand-written radix sort of those compact keys takes three passes of at most 9 bits instead of the four
+ * 8-bit passes of the general 32-bit sort.  Same result as nnc_sort_pruned_f32. */
+int32_t nnc_sort_pruned_bounded_bits(float vmin, float vmax, float thr, int64_t n_neg, int64_t n_pos);
+size_t nnc_sort_pruned_bounded_workspace_bytes(int64_t n_nonzero);
+int nnc_sort_pruned_bounded_f32(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float vmin, float vmax, float thr,
+                                float *sorted_out, void *ws, size_t ws_bytes, void *stream);
+
 /* The statistics of one whole vector by one call (what np.mean / np.var of the reference's KMeans set-up,
  * sklearn _kmeans.py:1011 / 286, and the pass above deliver one by one): out6_dev = {mean, variance (both
  * NumPy-exact float32, as nnc_chunk_sums_f32 + nnc_fold_f32), min, max, min over the non-zeros, max over the

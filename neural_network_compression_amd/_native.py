@@ -74,6 +74,9 @@ SIGNATURES = {
     "nnc_fold_f32": (c_int, [c_void_p, c_i64, c_i64, c_int, c_void_p, c_void_p, c_void_p]),
     "nnc_prune_workspace_bytes": (c_size, [c_i64]),
     "nnc_prune_f32": (c_int, [c_void_p, c_i64, c_f32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
+    "nnc_sort_pruned_bounded_bits": (c_i32, [c_f32, c_f32, c_f32, c_i64, c_i64]),
+    "nnc_sort_pruned_bounded_workspace_bytes": (c_size, [c_i64]),
+    "nnc_sort_pruned_bounded_f32": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_prune_stats_workspace_bytes": (c_size, [c_i64]),
     "nnc_prune_stats_f32": (c_int, [c_void_p, c_i64, c_f32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_threshold_mask_f32": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),

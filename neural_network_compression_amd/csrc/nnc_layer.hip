@@ -165,7 +165,8 @@ static LayerLayout layer_layout(int64_t n, int32_t k)
     L.prune_ws_bytes = nnc_prune_stats_workspace_bytes(n);
     L.stats_ws_bytes = std::max(nnc_layer_stats_workspace_bytes(n), nnc_minmax_workspace_bytes(n));
     // the pruned sort is taken when at least a quarter of the weights are zero: its workspace is largest at exactly a quarter
-    L.sort_ws_bytes = std::max(nnc_sort_workspace_bytes(n), nnc_sort_pruned_workspace_bytes(n, 0, (n + 3) / 4));
+    L.sort_ws_bytes = std::max(std::max(nnc_sort_workspace_bytes(n), nnc_sort_pruned_workspace_bytes(n, 0, (n + 3) / 4)),
+                               nnc_sort_pruned_bounded_workspace_bytes(n - (n + 3) / 4));
     L.km_ws_bytes = nnc_kmeans_workspace_bytes(k);
     L.prefix_bytes = nnc_kmeans_prefix_bytes(n);
     L.reloc_bytes = n >= 512 ? nnc_kmeans_reloc_scratch_bytes(k, 256) : 0;
@@ -296,7 +297,10 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         LCHK(nnc_fold_f32(c2, nch, n, NNC_FOLD_MEAN, nullptr, out6 + 1, side->stream));       // [1] = variance
         LHIP(hipEventRecord(side->join, side->stream));
         float *xs = reinterpret_cast<float *>(wb + L.sorted);
-        if (4 * n_zero >= n) LCHK(nnc_sort_pruned_f32(x, n, n_neg, n_zero, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
+        // (a pruned tensor whose threshold is known: the surviving weights span few key bits -- three radix passes instead of four)
+        if (4 * n_zero >= n && lp->prune && nnc_sort_pruned_bounded_bits(xmin, xmax, h_prune[1], n_neg, n - n_neg - n_zero) > 0)
+            LCHK(nnc_sort_pruned_bounded_f32(x, n, n_neg, n_zero, xmin, xmax, h_prune[1], xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
+        else if (4 * n_zero >= n) LCHK(nnc_sort_pruned_f32(x, n, n_neg, n_zero, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
         else LCHK(nnc_sort_f32(x, n, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
         const bool with_prefix = (reinterpret_cast<uintptr_t>(xs) & 15) == 0;
         int64_t *ranks_d = reinterpret_cast<int64_t *>(wb + L.stats_out + 64);

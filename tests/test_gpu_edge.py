@@ -278,3 +278,44 @@ def test_prune_with_statistics_in_one_pass(km_mod, n):
         mm1, sg1 = ops.minmax_signs(c)
         m2, s2, z2, mm2, sg2 = ops.prune_stats_(d, 1.0, True)
         assert torch.equal(c, d) and torch.equal(m1, m2) and torch.equal(mm1, mm2) and torch.equal(sg1, sg2)
+
+
+@pytest.mark.parametrize("n", [1, 7, 64, 4095, 4096, 4097, 70_001, 1_048_576, 3_000_017])
+def test_bounded_sort_of_a_pruned_vector(km_mod, n):
+    """nnc_sort_pruned_bounded_f32 (hand-written radix sort of compact keys) = a plain ascending sort."""
+    import ctypes
+    from neural_network_compression_amd import _native as nat
+
+    _, ops = km_mod
+    L = nat.load()
+    rs = np.random.RandomState(n % 1000)
+    for case in range(4):
+        w = synth.weights((n,), 6600 + case + n % 89, scale=float([0.05, 3.0, 1e-3, 0.05][case]))
+        if case == 2:
+            w = np.abs(w)                                   # one sign only
+        if case == 3 and n > 10:
+            w[rs.randint(0, n, size=n // 3)] = w[0]         # many equal values
+        x = torch.from_numpy(w.copy()).cuda()
+        q = [1.0, 0.5, 1.5, 1.0][case]
+        mask, stats, nz, mm, signs = ops.prune_stats_(x, q, True)
+        thr = float(stats.cpu().numpy()[1])
+        mmh, sg = mm.cpu().numpy(), signs.cpu().numpy()
+        n_neg, n_zero = int(sg[0]), int(sg[1])
+        bits = int(L.nnc_sort_pruned_bounded_bits(float(mmh[0]), float(mmh[1]), thr, n_neg, n - n_neg - n_zero))
+        if n_neg + n_zero == n and n_zero == n:
+            continue                                          # everything pruned: nothing to sort
+        if not thr > 0:
+            assert bits == 0                                  # (a single weight: sigma 0, no threshold, the form does not apply)
+            continue
+        assert 0 < bits <= 27, (n, case, bits, thr, mmh)
+        out = torch.empty_like(x)
+        wsb = int(L.nnc_sort_pruned_bounded_workspace_bytes(n - n_zero))
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        nat.check(L.nnc_sort_pruned_bounded_f32(x.data_ptr(), n, n_neg, n_zero, float(mmh[0]), float(mmh[1]), thr, out.data_ptr(), ws.data_ptr(), wsb,
+                                                torch.cuda.current_stream().cuda_stream))
+        want = torch.sort(x).values
+        assert torch.equal(out, want), (n, case, int((out != want).sum()))
+    # the form does not apply: no threshold, or a range of more than 27 bits
+    assert L.nnc_sort_pruned_bounded_bits(-1.0, 1.0, 0.0, 5, 5) == 0
+    assert L.nnc_sort_pruned_bounded_bits(-1.0, 1.0, 1e-30, 5, 5) == 0
+    assert L.nnc_sort_pruned_bounded_bits(-0.5, 0.5, 0.06, 5, 5) == 26
