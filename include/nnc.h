@@ -186,7 +186,7 @@ typedef struct nnc_kmeans_params {
     int32_t fix_shift; /* S of the fixed-point sums, from nnc_fix_shift() */
     int32_t grid_log2; /* log2 of the number of cells of the search grid; 0 = library default */
     int32_t replicas_log2; /* log2 of LDS accumulator replicas; -1 = library default */
-    int32_t flags;     /* reserved, 0 */
+    int32_t flags;     /* 0, or NNC_KM_TWO_LAUNCH */
     float x_mean;      /* NumPy float32 mean of the whole vector */
     float tol;         /* float32(np.var(x)) * float32(1e-4) */
     float lo, hi;      /* min and max of the centred data x - x_mean (float32) */
@@ -194,6 +194,11 @@ typedef struct nnc_kmeans_params {
                           Else it is sorted ascending (nnc_sort_f32) and prefix_dev the block prefix sums built from it by
                           nnc_kmeans_prefix_build: an iteration then only looks up the K - 1 cluster boundaries (below) */
 } nnc_kmeans_params;
+
+/* flags: iterate launch by launch (k_bounds + k_finalize per iteration, or k_fit_small for few centres) even where the
+ * one-workgroup loop (below, "The Lloyd loop in one workgroup") applies: for comparison and for the tests that pin the two forms
+ * to each other; same results. */
+#define NNC_KM_TWO_LAUNCH 1
 
 typedef struct nnc_kmeans_status {
     int32_t iter;      /* completed Lloyd iterations (scikit-learn's n_iter_ when done) */
@@ -212,7 +217,7 @@ typedef struct nnc_kmeans_status {
                             is the order numpy.argpartition leaves (implementation defined); here: descending distance */
     int32_t n_relocated; /* relocation events the device settled without the host (nnc_kmeans_fit enqueues the windowed relocation
                             behind the iterations of a batch in case they pause; it does nothing when they do not) */
-    int32_t reserved;
+    int32_t n_unproven;  /* ... and the events such a chain met but could not prove (the fit then pauses with paused == 2) */
 } nnc_kmeans_status;
 
 int32_t nnc_fix_shift(float absmax, int64_t n_total);
@@ -227,6 +232,15 @@ size_t nnc_kmeans_workspace_bytes(int32_t k);
  * prefix_dev: nnc_kmeans_prefix_bytes(n) bytes (per-block prefixes inside groups of 1024 blocks, then the group prefixes); build once per fit, after nnc_kmeans_init's x_mean / fix_shift are known.
  * x_sorted must be 16-byte aligned. */
 #define NNC_PREFIX_BLOCK 256
+/* The Lloyd loop in one workgroup (csrc/nnc_lloyd.hpp, k_lloyd): with prefix_dev set and the whole vector on one GPU
+ * (n == n_total), nnc_kmeans_iterate / nnc_kmeans_iterate_publish / nnc_kmeans_fit run the iterations inside ONE resident
+ * workgroup -- centres, zones, sums and counts in LDS; a boundary = a Newton step on the rank function from where it was last
+ * time, read as 64 samples + one 8-byte fine prefix (three cache lines) -- instead of two launches per iteration; an empty
+ * cluster ends the launch (status.paused, as always) and an iteration in which three or more centres sit within float32
+ * rounding of each other is run by the k_bounds / k_finalize pair enqueued behind every launch of the loop.  Bit-identical
+ * trajectory.  The buffer therefore also holds the fine prefixes (one int64 per 64 samples) behind the block / group prefixes.
+ * nnc_kmeans_iterate(iters) on this path enqueues min(iters, 32) rounds, each of which runs at least one iteration and all of
+ * which together run at most `iters`. */
 size_t nnc_kmeans_prefix_bytes(int64_t n);
 int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_params *p, int64_t *prefix_dev, void *stream);
 
@@ -536,6 +550,7 @@ int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void
 #define NNC_PROF_FINALIZE 5          /* k_finalize (K-sized) */
 #define NNC_PROF_PREFIX 6            /* k_prefix_blocks */
 #define NNC_PROF_MINMAX 7            /* k_minmax */
+#define NNC_PROF_LLOYD 8             /* k_lloyd: the one-workgroup Lloyd loop (any number of iterations per launch) */
 /* Which tags get events from now on (bit t = NNC_PROF_* tag t; default all): an event pair costs its launch a little, so a
  * timed run may want the passes over the vector only. */
 int nnc_profile_tags(uint32_t mask);

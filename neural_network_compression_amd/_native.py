@@ -21,6 +21,7 @@ NNC_OK = 0
 NNC_KMAX = 1040
 NNC_CHUNK = 8192
 FOLD_SUM, FOLD_MEAN, FOLD_STD = 0, 1, 2
+NNC_KM_TWO_LAUNCH = 1   # nnc_kmeans_params.flags: iterate launch by launch (include/nnc.h)
 
 
 class NativeLibraryError(RuntimeError):
@@ -46,7 +47,7 @@ class KMeansStatus(ctypes.Structure):
     _fields_ = [
         ("iter", c_i32), ("done", c_i32), ("paused", c_i32), ("n_empty", c_i32),
         ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("same_counts", c_i32),
-        ("reloc_ties", c_i32), ("reloc_multi", c_i32), ("n_relocated", c_i32), ("reserved", c_i32),
+        ("reloc_ties", c_i32), ("reloc_multi", c_i32), ("n_relocated", c_i32), ("n_unproven", c_i32),
     ]
 
 

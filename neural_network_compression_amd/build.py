@@ -30,7 +30,7 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + [os.path.join(INCLUDE, "nnc.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "nnc.h"), os.path.join(CSRC, "nnc_lloyd.hpp")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -948,6 +948,11 @@ struct KmWs {
     long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
     int32_t q_next[NNC_KMAX];
+    // k_lloyd (the one-workgroup loop, nnc_lloyd.hpp): `wide` = the next iteration needs the multi-workgroup pass (centres closer
+    // than float32 can tell apart, a search that did not settle): the k_bounds / k_finalize pair enqueued behind the loop "in case"
+    // runs only then and clears it; kl_budget = iterations the launches of the current host call may still run
+    int32_t wide, kl_budget;
+    float kl_hL[NNC_KMAX], kl_hR[NNC_KMAX]; // per boundary: the threshold its rank (hint_a) was found for, and the local density there (samples per unit)
     KmTab tab[2];
 };
 
@@ -1589,6 +1594,12 @@ __device__ __forceinline__ double wave_min_d(double v)
 // the group prefixes live behind the block prefixes in the caller's buffer
 __host__ __device__ __forceinline__ long long km_prefix_nblk(long long n) { return (n + NNC_PREFIX_BLOCK - 1) / NNC_PREFIX_BLOCK; }
 __device__ __forceinline__ const long long *km_pgrp(const long long *pblk, long long n) { return pblk + km_prefix_nblk(n) + 2; }
+// ... and behind those the FINE prefixes: entry i = sum of fix(x~) over the first 64 * i samples (i = 0 .. 4 * nblk; every entry from
+// ceil(n / 64) on holds the total), what the one-workgroup loop (k_lloyd) reads: one 8-byte entry and the 256 bytes of the
+// sorted vector it stands in front of give the prefix sum at any rank
+#define KL_BLK 64
+__host__ __device__ __forceinline__ long long km_prefix_ngroups(long long n) { return (km_prefix_nblk(n) + 1 + KM_PG - 1) / KM_PG; }
+__host__ __device__ __forceinline__ long long km_pfine_off(long long n) { return km_prefix_nblk(n) + 2 + km_prefix_ngroups(n) + 2; }
 
 // sum of fix(x~) over the first r samples: block prefix + the wave adds the rest of r's block
 __device__ __forceinline__ long long km_prefix_at(const float *__restrict__ xs, const long long *__restrict__ pblk, long long r,
@@ -2017,10 +2028,11 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
     }
     const int stop = (which & 2) ? 0 : (ws->st.done | ws->st.paused); // (which & 2: counting pass after the fit)
+    const int unasked = (which & 4) ? !ws->wide : 0; // (which & 4: enqueued behind k_lloyd in case it hands an iteration over)
     const int hint = ws->help_hint;
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
-    if (stop) return;
+    if (stop | unasked) return;
     // workgroups beyond the boundary waves (nbnd_wg of them) only share long undecided stretches; everybody stays until every
     // boundary wave has said that it has nothing more to publish
     bool published = false;
@@ -2043,6 +2055,7 @@ __global__ __launch_bounds__(256) void k_prefix_blocks(const float *__restrict__
 {
     const int lane = threadIdx.x & 63;
     const long long nblk = (n + KM_PB - 1) / KM_PB;
+    long long *__restrict__ pfine = pblk + km_pfine_off(n); // (here: the raw sums of the 64-sample quarters; k_prefix_fine turns them into prefixes)
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
     for (long long b = wave; b < nblk; b += nwaves) {
         const long long i0 = b * KM_PB + 4 * lane;
@@ -2053,10 +2066,28 @@ __global__ __launch_bounds__(256) void k_prefix_blocks(const float *__restrict__
         } else {
             for (int u = 0; u < 4; u++) if (i0 + u < n) acc += fix_f32(xs[i0 + u] - mean, Sft);
         }
-        acc = wave_sum_ll(acc);
+#pragma unroll
+        for (int off = 1; off <= 8; off <<= 1) acc += __shfl_xor(acc, off); // sixteen lanes = one quarter (64 samples)
+        if ((lane & 15) == 0) pfine[4 * b + (lane >> 4)] = acc;
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
         if (lane == 0) pblk[b] = acc;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) pblk[nblk] = 0; // one virtual block behind the last: its prefix is the total
+}
+
+// fine prefixes from the scanned block / group prefixes and the quarters' raw sums (in place; one thread per 256-sample block)
+__global__ __launch_bounds__(256) void k_prefix_fine(long long *__restrict__ pblk, long long n)
+{
+    const long long nblk = km_prefix_nblk(n);
+    const long long *__restrict__ pgrp = km_pgrp(pblk, n);
+    long long *__restrict__ pfine = pblk + km_pfine_off(n);
+    const long long b = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (b > nblk) return;
+    const long long base = pblk[b] + pgrp[b / KM_PG];
+    if (b == nblk) { pfine[4 * b] = base; return; } // the total
+    const long long q0 = pfine[4 * b], q1 = pfine[4 * b + 1], q2 = pfine[4 * b + 2];
+    pfine[4 * b] = base; pfine[4 * b + 1] = base + q0; pfine[4 * b + 2] = base + q0 + q1; pfine[4 * b + 3] = base + q0 + q1 + q2;
 }
 
 // Two-level exclusive scan of the block sums: groups of KM_PG blocks, one workgroup per group (pblk[b] becomes the sum of the
@@ -2565,8 +2596,17 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
     __shared__ int fin_go, fin_kc[2], fin_novf; // fin_kc: {distinct centres, current table} from the body
+    __shared__ int fin_asked;
     const int tid = threadIdx.x;
-    if (FUSED) {
+    const int cond = lazy & 2; // enqueued behind k_lloyd in case it hands an iteration over (ws->wide): nothing to do otherwise
+    lazy &= 1;
+    if (cond) {
+        if (tid == 0) fin_asked = ws->wide;
+        __syncthreads();
+    }
+    if (cond && !fin_asked) {
+        // (fall through to the look-in)
+    } else if (FUSED) {
         const int glog2 = ws->glog2; // (constant over the fit: the helpers may read it at once)
         if (tid == 0) { fin_go = 0; fin_novf = 0; }
         __syncthreads();
@@ -2585,6 +2625,10 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
         }
     } else {
         km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0);
+    }
+    if (cond && fin_asked) { // the iteration k_lloyd handed over has been run (or has paused): the loop may go on
+        __syncthreads();
+        if (tid == 0) { ws->wide = 0; ws->kl_budget = ws->kl_budget - 1; }
     }
     if (host_st) {
         __syncthreads();
@@ -2718,6 +2762,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     km_cells_body(ws, host_st, host_ticket, ticket, force, which, spec, (int)blockIdx.x);
 }
 
+#include "nnc_lloyd.hpp"
+
 static bool km_fused(const nnc_kmeans_params *p)
 {
     int glog2, rlog2;
@@ -2744,7 +2790,7 @@ static int km_ensure_cells(KmWs *w, const nnc_kmeans_params *p, int which, void 
 }
 
 static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume, void *stream, void *host_mapped = nullptr,
-                              uint64_t ticket = 0)
+                              uint64_t ticket = 0, bool cond = false)
 {
     // p == nullptr: the caller does not know the fit's parameters (nnc_kmeans_finalize): full width, k_cells builds the table
     const int k = p ? p->k : 0;
@@ -2756,7 +2802,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
     nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
-#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, lazy ? 1 : 0)
+#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0))
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
     else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256); // (measured at K = 257: one wave 23.6 us, four waves 14.6 / 17.7 us median / mean, sixteen 14.4 / 15.9)
@@ -2786,7 +2832,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
         ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
-        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0; ws->st.n_relocated = 0; ws->st.reserved = 0; ws->spec_go = 0;
+        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0; ws->st.n_relocated = 0; ws->st.n_unproven = 0; ws->spec_go = 0;
         ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0; ws->cells_pending = 0;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
@@ -2798,7 +2844,8 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
-    if (tid == 0) { ws->q_n = 0; ws->q_done = 0; ws->help_hint = 0; ws->help_pad = 0; }
+    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->kl_hL[i] = 0.0f; ws->kl_hR[i] = 0.0f; }
+    if (tid == 0) { ws->q_n = 0; ws->q_done = 0; ws->help_hint = 0; ws->help_pad = 0; ws->wide = 0; ws->kl_budget = 0; }
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -2901,7 +2948,7 @@ extern "C" size_t nnc_kmeans_prefix_bytes(int64_t n)
 {
     if (n < 0) return 0;
     const long long nblk = (n + KM_PB - 1) / KM_PB;
-    return (size_t)(nblk + 2 + (nblk + 1 + KM_PG - 1) / KM_PG + 2) * sizeof(long long);
+    return (size_t)(nblk + 2 + (nblk + 1 + KM_PG - 1) / KM_PG + 2 + 4 * (nblk + 1) + 4) * sizeof(long long);
 }
 
 extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_params *p, int64_t *prefix_dev, void *stream)
@@ -2923,6 +2970,8 @@ extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_p
     }
     hipLaunchKernelGGL(k_prefix_top, dim3(1), dim3(KM_THREADS), 0, S(stream), pg, ngroups);
     LAUNCHCHK("k_prefix_top");
+    hipLaunchKernelGGL(k_prefix_fine, dim3((unsigned)((nblk + 1 + 255) / 256)), dim3(256), 0, S(stream), pb, (long long)p->n);
+    LAUNCHCHK("k_prefix_fine");
     return NNC_OK;
 }
 
@@ -2966,6 +3015,40 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     return NNC_OK;
 }
 
+// ---- the one-workgroup loop (nnc_lloyd.hpp) and, behind it, the wide pair in case it hands an iteration over --------------------
+static bool km_lloyd_ok(const nnc_kmeans_params *p, const float *x)
+{
+    return p->prefix_dev && p->n > 0 && p->n == p->n_total && !(p->flags & NNC_KM_TWO_LAUNCH) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+}
+
+static int km_launch_lloyd(const float *xs, KmWs *w, const nnc_kmeans_params *p, int budget_set, void *stream)
+{
+    const int kc = (p->k + 7) & ~7;
+    const size_t lds = kl_lds_bytes(kc);
+    const long long *pb = reinterpret_cast<const long long *>(p->prefix_dev);
+    if (p->k <= 128)
+        NNC_LAUNCH_PROF(NNC_PROF_LLOYD, (k_lloyd<256>), dim3(1), dim3(256), lds, S(stream), xs, (long long)p->n, w, pb, budget_set, kc,
+                        (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull);
+    else
+        NNC_LAUNCH_PROF(NNC_PROF_LLOYD, (k_lloyd<KM_THREADS>), dim3(1), dim3(KM_THREADS), lds, S(stream), xs, (long long)p->n, w, pb, budget_set, kc,
+                        (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull);
+    LAUNCHCHK("k_lloyd");
+    return NNC_OK;
+}
+
+// one round: the loop runs until the fit stops, pauses, or an iteration needs the wide pass; k_bounds / k_finalize then run that one
+// iteration (they return at once otherwise).  The look-in, if any, rides on the last launch.
+static int km_launch_lloyd_round(const float *xs, KmWs *w, const nnc_kmeans_params *p, int budget_set, void *stream, void *host_mapped = nullptr,
+                                 uint64_t ticket = 0)
+{
+    int rc;
+    if ((rc = km_launch_lloyd(xs, w, p, budget_set, stream))) return rc;
+    if ((rc = km_launch_accumulate(xs, w, p, stream, 4))) return rc;
+    return km_launch_finalize(w, p, FIN_FROM_SHARDS, 0, stream, host_mapped, ticket, true);
+}
+#define KM_LLOYD_ROUNDS_MAX 32 // rounds one nnc_kmeans_iterate call enqueues at most (a round runs at least one iteration)
+#define KM_LLOYD_ROUNDS 6      // rounds nnc_kmeans_fit enqueues per look-in
+
 static std::atomic<int> g_lds_attr_set[NNC_MAX_DEVICES]; // function attributes are per device
 static int km_set_lds_attr()
 {
@@ -2986,6 +3069,9 @@ static int km_set_lds_attr()
     SETATTR((k_assign<1, true, uint16_t>));
     SETATTR((k_assign<1, false, uint16_t>));
 #undef SETATTR
+    // (k_lloyd has a little static LDS of its own -- the workgroup votes -- so it cannot ask for all 160 KiB; K = NNC_KMAX needs 119 KiB)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd<KM_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     g_lds_attr_set[dev].store(1, std::memory_order_release);
     return NNC_OK;
 }
@@ -3023,6 +3109,13 @@ extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_par
     if (p.n != p.n_total) return fail(NNC_EINVAL, "nnc_kmeans_iterate: sharded vector (n != n_total) needs accumulate / all-reduce / finalize");
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if (km_lloyd_ok(&p, x)) {
+        // the one-workgroup loop; every round runs at least one iteration (its own, or the one it hands to the wide pair behind it)
+        const int rounds = std::min<int>(iters, KM_LLOYD_ROUNDS_MAX);
+        for (int r = 0; r < rounds; r++)
+            if ((rc = km_launch_lloyd_round(x, w, &p, r == 0 ? (int)iters : -1, stream))) return rc;
+        return NNC_OK;
+    }
     if (km_one_launch_fit(&p, x)) {
         if (iters < 1) return NNC_OK;
         hipLaunchKernelGGL(k_fit_small, dim3(1), dim3(KM_THREADS), 0, S(stream), x, (long long)p.n, w, reinterpret_cast<const long long *>(p.prefix_dev),
@@ -3089,6 +3182,12 @@ extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_km
         return fail(NNC_EINVAL, "nnc_kmeans_iterate_publish: iters < 1, or null / unaligned host pointer");
     if ((rc = km_set_lds_attr())) return rc;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+    if (km_lloyd_ok(&p, x)) {
+        const int rounds = std::min<int>(iters, KM_LLOYD_ROUNDS_MAX);
+        for (int r = 0; r < rounds; r++)
+            if ((rc = km_launch_lloyd_round(x, w, &p, r == 0 ? (int)iters : -1, stream, r == rounds - 1 ? host_mapped : nullptr, ticket))) return rc;
+        return NNC_OK;
+    }
     if (km_one_launch_fit(&p, x)) {
         unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
         hipLaunchKernelGGL(k_fit_small, dim3(1), dim3(KM_THREADS), 0, S(stream), x, (long long)p.n, w, reinterpret_cast<const long long *>(p.prefix_dev),
@@ -4076,7 +4175,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     {
         int bad0 = meta[2] ? 1 : 0;
         if (n_empty < 1 || n_cand < n_empty) bad0 |= 2;
-        if (bad0) { if (tid == 0) ws->reloc_fail = bad0; return; }
+        if (bad0) { if (tid == 0) { ws->reloc_fail = bad0; if (spec) ws->st.n_unproven += 1; } return; }
     }
     // Coalesced 16-byte reads; neighbours in position have similar distances, so most of the time a
     // whole wave lands in one bin: one LDS atomic per wave instead of 256 (LDS atomics retire about
@@ -4277,7 +4376,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
     __syncthreads();
     RSTAMP(4);
     const int any_bad = s_bad;
-    if (tid == 0) ws->reloc_fail = any_bad;
+    if (tid == 0) { ws->reloc_fail = any_bad; if (spec && any_bad) ws->st.n_unproven += 1; }
     if (any_bad || !do_relocate) return; // (sharded vector: the ranks first exchange their keys and their verdicts)
     __threadfence_block();
     km_relocate_apply(ws, keys_out, min(m, n_empty + 1), n_empty_ws, &rl);
@@ -4481,7 +4580,8 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
     const nnc_kmeans_params p = *pp;
     if (p.n != p.n_total) return fail(NNC_EINVAL, "nnc_kmeans_fit: single GPU only (sharded fits: nnc_kmeans_iterate_sharded)");
     if (max_batch < 1) max_batch = 1;
-    const bool one_launch = km_one_launch_fit(&p, x_iter);
+    const bool lloyd = km_lloyd_ok(&p, x_iter);
+    const bool one_launch = !lloyd && km_one_launch_fit(&p, x_iter);
     const size_t slot = sizeof(nnc_kmeans_status) + 8;
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped); // two slots, used alternately
     // Empty clusters come in runs (duplicate initial centres: the bench fit pauses in iterations 0-9, 11, 16, 19), and an event
@@ -4492,15 +4592,25 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
                          reloc_scratch_bytes >= nnc_kmeans_reloc_scratch_bytes(p.k, KM_SPEC_WMAX) && p.n >= 2 * KM_SPEC_WMAX;
     bool spec = spec_ok;
     int batch = one_launch ? p.max_iter : (spec ? 12 : 1); // the first iteration is where duplicate initial centres surface as empty clusters
-    int nwin = 0, nrel_seen = status_out->n_relocated; // (a call after a full-pass relocation carries on from the last status)
-    if (!spec_ok) nrel_seen = 0;
+    if (lloyd) batch = KM_LLOYD_ROUNDS; // rounds per look-in: a round ends at an empty cluster (settled by the chain behind it, if there is one) or a handed-over iteration
+    bool first_launch = true;
+    int nwin = 0, nrel_seen = status_out->n_relocated, nunp_seen = status_out->n_unproven; // (a call after a full-pass relocation carries on from the last status)
+    if (!spec_ok) { nrel_seen = 0; nunp_seen = 0; }
     double s_prev = -1.0, s_last = -1.0;
     int i_prev = 0, i_last = 0;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
     for (;;) {
         const uint64_t ticket = ++(*ticket_io);
         unsigned char *sl = hb + (ticket & 1) * slot;
-        if (spec) {
+        if (lloyd) {
+            if ((rc = km_set_lds_attr())) return rc;
+            for (int i = 0; i < batch; i++) {
+                const bool last = i == batch - 1;
+                if ((rc = km_launch_lloyd_round(x_iter, w, &p, first_launch ? p.max_iter : -1, stream, (last && !spec) ? sl : nullptr, ticket))) return rc;
+                first_launch = false;
+                if (spec && (rc = km_launch_spec_reloc(x_iter, w, &p, reloc_scratch_dev, stream, last ? sl : nullptr, ticket))) return rc;
+            }
+        } else if (spec) {
             if ((rc = km_set_lds_attr())) return rc;
             for (int i = 0; i < batch; i++) {
                 if ((rc = km_launch_accumulate(x_iter, w, &p, stream))) return rc;
@@ -4514,7 +4624,12 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
         const int dev_events = spec_ok ? st.n_relocated - nrel_seen : 0; // events the device settled by itself in this batch
         nrel_seen = st.n_relocated;
         nwin += dev_events;
+        // an unproven windowed selection comes back as paused == 2 and the caller takes one windowed event back before it redoes
+        // it in full: the attempts of the chains enqueued "in case" are counted like the ones this loop asks for itself
+        nwin += spec_ok ? st.n_unproven - nunp_seen : 0;
+        nunp_seen = st.n_unproven;
         if (st.done) break;
+        if (lloyd && !st.paused) continue; // every round met an event the device settled: the same number of rounds again
         if (spec && !st.paused) {
             // a chain that finds nothing to do still costs its five launches (about as much as the round trip it would have saved):
             // carry on only while most iterations pause
@@ -4528,7 +4643,7 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
             if (window == 0 || !reloc_scratch_dev || reloc_scratch_bytes < nnc_kmeans_reloc_scratch_bytes(p.k, window)) break; // the caller's turn
             if ((rc = nnc_kmeans_relocate_windowed(x_iter, ws, &p, st.n_empty, reloc_scratch_dev, reloc_scratch_bytes, stream))) return rc;
             nwin++;
-            batch = one_launch ? p.max_iter : 1;
+            if (!lloyd) batch = one_launch ? p.max_iter : 1;
             s_prev = s_last = -1.0;
             continue;
         }

@@ -242,7 +242,8 @@ class DeviceKMeans:
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
                  batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
                  reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
-                 n_total: int | None = None, n_min: int | None = None, comm=None, rank_boundaries: bool = True):
+                 n_total: int | None = None, n_min: int | None = None, comm=None, rank_boundaries: bool = True,
+                 two_launch: bool = False):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -291,7 +292,7 @@ class DeviceKMeans:
         self.fix_shift = ops.fix_shift(absmax, n_total)
 
         self.p = nat.KMeansParams(n=n, n_total=n_total, k=self.k, max_iter=int(max_iter), fix_shift=self.fix_shift,
-                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=0,
+                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=nat.NNC_KM_TWO_LAUNCH if two_launch else 0,
                                   x_mean=float(mean), tol=float(self.tol_), lo=float(lo), hi=float(hi))
         self.ws_bytes = self.L.nnc_kmeans_workspace_bytes(self.k)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
@@ -343,7 +344,10 @@ class DeviceKMeans:
             self.p.prefix_dev = self.prefix.data_ptr()
         # few centres on one GPU: the library runs a whole batch of iterations as ONE launch that stops by itself at
         # convergence or at an empty cluster (include/nnc.h, nnc_kmeans_iterate_publish), so there is nothing to size
-        self.one_launch = self.prefix is not None and group is None and self.k <= 64 and int(grid_log2) <= 11
+        # the whole vector on one GPU, sorted, with prefix sums: the iterations run inside ONE resident workgroup (include/nnc.h,
+        # "The Lloyd loop in one workgroup"); two_launch=True keeps the launch-per-iteration forms (same results)
+        self.lloyd = self.prefix is not None and group is None and not two_launch
+        self.one_launch = self.prefix is not None and group is None and self.k <= 64 and int(grid_log2) <= 11 and not self.lloyd
 
     # -------------------------------------------------------------- low-level steps
     def publish(self) -> int:
