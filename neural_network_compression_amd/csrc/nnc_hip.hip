@@ -943,7 +943,7 @@ struct KmWs {
     // what k_bounds needs of the CURRENT table, at an address that does not depend on which of the two tables is current
     // (one round of loads less at the head of every iteration); k_finalize writes it next to tab[cur]
     struct Bnd { int32_t ku, pad; double zr[NNC_KMAX], zl[NNC_KMAX]; float2 cand[NNC_KMAX]; uint16_t orig[NNC_KMAX]; } bnd;
-    int32_t q_n, q_done; // records published; waves of the launch that have nothing left to publish
+    int32_t q_n, q_pad; // records published
     int32_t help_hint, help_pad; // the previous pass published long stretches: this one had better look at the queue (k_finalize sets it)
     long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
@@ -1669,7 +1669,10 @@ __device__ __forceinline__ void km_shard_add(KmWs *ws, int p, long long sum, uns
 }
 
 // exact labels of the samples [s, e) whose candidates are the centres plo .. phi (value order), added to the sums
-__device__ __attribute__((noinline)) void km_bounds_range(const float *__restrict__ xs, long long s, long long e, int plo, int phi, const KmTab *__restrict__ tab,
+// (Inlined again: round 2 made this a real call because the inlined form hung in the tile loop of k_bounds.  The call only hid the
+// cause -- a ticket produced under `if (lane == 0)` and read with v_readfirstlane, see km_claim below, which is where it is fixed;
+// with that the claim loop compiles to a scalar loop around this body, 83 VGPRs and no scratch instead of 90 + 64 bytes.)
+__device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, long long s, long long e, int plo, int phi, const KmTab *__restrict__ tab,
                                                         KmWs *ws, float mean, int Sft, int lane)
 {
     s = uni_ll(s); e = uni_ll(e); plo = uni_i(plo); phi = uni_i(phi);
@@ -1778,11 +1781,25 @@ __device__ __attribute__((noinline)) void km_bounds_range(const float *__restric
     } else if (run_n) km_shard_add(ws, run_p, run_s, run_n);
 }
 
+// A ticket for the whole wave.  EVERY lane runs the atomic (lane 0 adds 1, the others 0; the compiler folds the wave's adds into
+// one), then lane 0's result is broadcast.  NOT "if (lane == 0) t = atomicAdd(...); t = readfirstlane(t)": v_readfirstlane reads the
+// first ACTIVE lane, so that form is only right while lane 0 is active at the read -- and nothing makes the compiler keep it so.
+// Round 2's hang was exactly that: with km_bounds_range inlined into the claim loop, the `if (lane == 0)` of its closing
+// km_shard_add and the `if (lane == 0)` of the next claim were threaded into ONE lane-0-only path around the loop's back edge; the
+// structurizer then sent lanes 1-63 round the loop ahead of lane 0 (ISA of fc02041^: the loop's continue mask is the lane-0 mask,
+// `s_mov_b64 s[0:1], s[8:9]` ... `s_andn2_b64 exec, exec, s[56:57]`, and `v_readfirstlane_b32 s2, v15` runs with exec = ~1), they
+// read their own zero as the ticket and ran tile 0 again, for ever.  A value one lane hands to the wave must be produced with
+// the whole wave active.
 __device__ __forceinline__ int km_claim(int *counter, int lane)
 {
-    int t = 0;
-    if (lane == 0) t = atomicAdd(counter, 1);
+    const int t = atomicAdd(counter, lane == 0 ? 1 : 0);
     return uni_i(t);
+}
+// the same rule for a word the wave polls: every lane loads it (one address, one request), nobody loads it for the others
+__device__ __forceinline__ int km_peek_i(const int *word) { return uni_i(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+__device__ __forceinline__ unsigned long long km_peek_ull(const unsigned long long *word)
+{
+    return (unsigned long long)uni_ll((long long)__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
 // wave j's share of one rank-boundary pass (see above): centre j's certain stretch and the undecided stretch above it
@@ -1923,9 +1940,7 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
         const bool quick = und > 0 && und <= 256 && phi == j + 1; // few samples, two candidates: settled right here
         // a long stretch goes out as tiles for everybody, and at once: the others look at the queue a round of loads from now
         if (und > KM_TILE) {
-            int r = 0;
-            if (lane == 0) r = atomicAdd(&ws->q_n, 1);
-            r = uni_i(r);
+            const int r = km_claim(&ws->q_n, lane);
             if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
                 published = true;
                 if (lane == 0) {
@@ -1945,7 +1960,7 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
             if (lane == 0) km_shard_add(ws, j, sum, (unsigned long long)(a - bm));
         }
         // (how many long stretches are out by now: asked here, looked at by the caller when this wave's own work is through)
-        if (lane == 0) *qn_seen = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *qn_seen = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (every lane: see km_claim)
         KBSTAMP(16 * j + 4, 0);
         if (quick) {
             long long s0 = 0, s1 = 0;
@@ -1968,52 +1983,33 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
     return published;
 }
 
-// tiles of long undecided stretches: every wave that comes through here helps
-// Tiles of long undecided stretches.  Every wave of the launch comes through here and takes tiles; with wait_for > 0 it stays
-// until that many waves have reported that they have nothing left to publish (q_done) and one more look at the queue after
-// that has found nothing to take -- so a stretch published late still finds the whole launch ready to share it.  A publisher
-// comes through here after its own record is out and leaves only when all its tiles are taken, so no tile depends on helpers.
+// Tiles of long undecided stretches: every wave of the launch that comes through here takes tiles from the records that are out.
+// A publisher comes through here after its own record is out and leaves only when all its tiles are taken, so no tile depends on
+// anybody else (nobody waits for anybody: a record a wave does not see yet is finished by its publisher).
 __device__ __forceinline__ void km_bounds_help(const int lane, const float *__restrict__ xs, KmWs *__restrict__ ws,
-                                               const KmTab *__restrict__ tab, const float mean, const int Sft, const int wait_for)
+                                               const KmTab *__restrict__ tab, const float mean, const int Sft)
 {
-    for (;;) {
-        int fin = 1, nrec = 0;
-        if (lane == 0) {
-            if (wait_for > 0) fin = __hip_atomic_load(&ws->q_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= wait_for; // before the look at the queue
-            // (relaxed on purpose: a record missed here is still finished by its publisher; an acquire per poll would drop the caches of a thousand waves)
-            nrec = __hip_atomic_load(&ws->q_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (relaxed on purpose: an acquire per look would drop the caches of a thousand waves)
+    const int nrec = min(km_peek_i(&ws->q_n), (int)NNC_KMAX);
+    for (int r = 0; r < nrec; r++) {
+        const unsigned long long w0 = km_peek_ull(&ws->q_w0[r]), w1 = km_peek_ull(&ws->q_w1[r]);
+        if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
+        const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
+        const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
+        const int ntiles = (int)((e - s + KM_TILE - 1) / KM_TILE);
+        if (km_peek_i(&ws->q_next[r]) >= ntiles) continue; // (spent: no need to bump its counter again)
+        int t = km_claim(&ws->q_next[r], lane);
+        while (t < ntiles) {
+            const long long ts = s + (long long)t * KM_TILE;
+            const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
+            km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
+            t = km_claim(&ws->q_next[r], lane);
         }
-        fin = uni_i(fin);
-        nrec = min(uni_i(nrec), (int)NNC_KMAX);
-        for (int r = 0; r < nrec; r++) {
-            unsigned long long w0 = 0, w1 = 0;
-            if (lane == 0) {
-                w0 = __hip_atomic_load(&ws->q_w0[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                w1 = __hip_atomic_load(&ws->q_w1[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            w0 = (unsigned long long)uni_ll((long long)w0); w1 = (unsigned long long)uni_ll((long long)w1);
-            if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
-            const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
-            const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
-            const int ntiles = (int)((e - s + KM_TILE - 1) / KM_TILE);
-            int taken = 0;
-            if (lane == 0) taken = __hip_atomic_load(&ws->q_next[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (uni_i(taken) >= ntiles) continue; // (spent: no need to bump its counter again)
-            int t = km_claim(&ws->q_next[r], lane);
-            while (t < ntiles) {
-                const long long ts = s + (long long)t * KM_TILE;
-                const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
-                km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
-                t = km_claim(&ws->q_next[r], lane);
-            }
-        }
-        if (fin) break;
-        __builtin_amdgcn_s_sleep(40);
     }
 }
 
 __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
-                                               const long long *__restrict__ pblk, int kmax, int nbnd_wg)
+                                               const long long *__restrict__ pblk, int kmax)
 {
     const int lane = threadIdx.x & 63;
     const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -2033,20 +2029,13 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     const float mean = ws->p.x_mean;
     const int Sft = ws->p.fix_shift;
     if (stop | unasked) return;
-    // workgroups beyond the boundary waves (nbnd_wg of them) only share long undecided stretches; everybody stays until every
-    // boundary wave has said that it has nothing more to publish
-    bool published = false;
-    int qn_seen = 0; // lane 0's: the number of long stretches that were out when this wave's own loads went out
-    const bool waiting = (int)gridDim.x > nbnd_wg;
-    if ((int)blockIdx.x < nbnd_wg) {
-        published = km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk, &qn_seen);
-        if (waiting && lane == 0) __hip_atomic_fetch_add(&ws->q_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    int qn_seen = 0; // the number of long stretches that were out when this wave's own loads went out
+    const bool published = km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk, &qn_seen);
     KBSTAMP(16 * j + 5, 0);
     // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
     // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
     // to see its own tiles through.
-    if (published || hint || waiting || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft, waiting ? 4 * nbnd_wg : 0);
+    if (published || hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
     KBSTAMP(16 * j + 6, 0);
 }
 
@@ -2182,7 +2171,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         const int qn = min(ws->q_n, (int)NNC_KMAX);
         for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
-        if (tid == 0) { ws->q_n = 0; ws->q_done = 0; ws->help_hint = qn > 0; }
+        if (tid == 0) { ws->q_n = 0; ws->help_hint = qn > 0; }
     }
     // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
     // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
@@ -2665,7 +2654,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         bool published = false;
         int qn_seen = 0;
         for (int j = wv; j < ku; j += KM_THREADS / 64) published |= km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk, &qn_seen);
-        if (published || ws->help_hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft, 0);
+        if (published || ws->help_hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
         // The sums went out as device-scope atomics (performed in L2); the first wave must not read them from a line its CU
         // still holds from the last round: drop the CU's cached copies (acquire), no write-back needed.
         __syncthreads();
@@ -2845,7 +2834,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->kl_hL[i] = 0.0f; ws->kl_hR[i] = 0.0f; }
-    if (tid == 0) { ws->q_n = 0; ws->q_done = 0; ws->help_hint = 0; ws->help_pad = 0; ws->wide = 0; ws->kl_budget = 0; }
+    if (tid == 0) { ws->q_n = 0; ws->help_hint = 0; ws->help_pad = 0; ws->wide = 0; ws->kl_budget = 0; }
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -2981,12 +2970,8 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
 {
     if (p->prefix_dev && p->n > 0) {
         if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
-        const int nb = (p->k + 3) / 4; // one wave per centre (distinct centres <= k)
-        // plus workgroups that only share long undecided stretches (centres closer than float32 can tell apart make thousands of
-        // samples undecided at once): all resident together on the chip's CUs, so waiting on each other is safe
-        int nh = (int)std::max<int64_t>(0, std::min<int64_t>(p->n / (64 * 1024), (int64_t)cu_count() - nb));
-        nh = 0; // (measured: a thousand waves waiting on the counter cost every launch 10 us and the long launches are not short of hands)
-        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(nb + nh), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k, nb);
+        const int nb = (p->k + 3) / 4; // one wave per centre (distinct centres <= k); long undecided stretches are shared by the waves that are still running
+        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(nb), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k);
         LAUNCHCHK("k_bounds");
         return NNC_OK;
     }
@@ -3141,7 +3126,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_counts_from_shards(KmWs *__restr
         const int qn = min(ws->q_n, (int)NNC_KMAX);
         for (int r = threadIdx.x; r < qn; r += KM_THREADS) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         __syncthreads();
-        if (threadIdx.x == 0) { ws->q_n = 0; ws->q_done = 0; }
+        if (threadIdx.x == 0) ws->q_n = 0;
     }
     for (int j = threadIdx.x; j < k; j += KM_THREADS) counts[j] = 0; // duplicates of a centre own nothing
     __syncthreads();
