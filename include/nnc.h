@@ -186,7 +186,7 @@ typedef struct nnc_kmeans_params {
     int32_t fix_shift; /* S of the fixed-point sums, from nnc_fix_shift() */
     int32_t grid_log2; /* log2 of the number of cells of the search grid; 0 = library default */
     int32_t replicas_log2; /* log2 of LDS accumulator replicas; -1 = library default */
-    int32_t flags;     /* 0, or NNC_KM_TWO_LAUNCH */
+    int32_t flags;     /* 0 (the library chooses), NNC_KM_TWO_LAUNCH or NNC_KM_LOOP */
     float x_mean;      /* NumPy float32 mean of the whole vector */
     float tol;         /* float32(np.var(x)) * float32(1e-4) */
     float lo, hi;      /* min and max of the centred data x - x_mean (float32) */
@@ -199,6 +199,11 @@ typedef struct nnc_kmeans_params {
  * one-workgroup loop (below, "The Lloyd loop in one workgroup") applies: for comparison and for the tests that pin the two forms
  * to each other; same results. */
 #define NNC_KM_TWO_LAUNCH 1
+/* ... and the other way round: the one-workgroup loop whatever the number of centres (by itself the library takes it up to
+ * NNC_KM_LOOP_KMAX centres, where one compute unit's instruction rate is not yet the bound: measured on 0.1 M - 25 M weights it
+ * takes 0.46 - 0.8 of the launch-per-iteration time up to K = 65, about the same at K = 129, 1.0 - 1.2 of it at K = 257). */
+#define NNC_KM_LOOP 2
+#define NNC_KM_LOOP_KMAX 192
 
 typedef struct nnc_kmeans_status {
     int32_t iter;      /* completed Lloyd iterations (scikit-learn's n_iter_ when done) */
@@ -232,16 +237,21 @@ size_t nnc_kmeans_workspace_bytes(int32_t k);
  * prefix_dev: nnc_kmeans_prefix_bytes(n) bytes (per-block prefixes inside groups of 1024 blocks, then the group prefixes); build once per fit, after nnc_kmeans_init's x_mean / fix_shift are known.
  * x_sorted must be 16-byte aligned. */
 #define NNC_PREFIX_BLOCK 256
-/* The Lloyd loop in one workgroup (csrc/nnc_lloyd.hpp, k_lloyd): with prefix_dev set and the whole vector on one GPU
- * (n == n_total), nnc_kmeans_iterate / nnc_kmeans_iterate_publish / nnc_kmeans_fit run the iterations inside ONE resident
- * workgroup -- centres, zones, sums and counts in LDS; a boundary = a Newton step on the rank function from where it was last
- * time, read as 64 samples + one 8-byte fine prefix (three cache lines) -- instead of two launches per iteration; an empty
- * cluster ends the launch (status.paused, as always) and an iteration in which three or more centres sit within float32
- * rounding of each other is run by the k_bounds / k_finalize pair enqueued behind every launch of the loop.  Bit-identical
- * trajectory.  The buffer therefore also holds the fine prefixes (one int64 per 64 samples) behind the block / group prefixes.
+/* The Lloyd loop in one workgroup (csrc/nnc_lloyd.hpp, k_lloyd): with prefix_dev set, the whole vector on one GPU
+ * (n == n_total) and at most NNC_KM_LOOP_KMAX centres (or flags = NNC_KM_LOOP), nnc_kmeans_iterate / nnc_kmeans_iterate_publish /
+ * nnc_kmeans_fit run the iterations inside ONE resident workgroup -- centres, zones, sums and counts in LDS; a rank = a Newton
+ * step on the rank function from where it was last time, read as 128 samples + two 8-byte fine prefixes -- instead of two launches
+ * per iteration; an empty cluster ends the launch (status.paused, as always) and an iteration with more than a million undecided
+ * samples is run by the k_bounds / k_finalize pair enqueued behind every launch of the loop.  Bit-identical trajectory.  The buffer
+ * therefore also holds the fine prefixes (one int64 per 64 samples) behind the block / group prefixes.
  * nnc_kmeans_iterate(iters) on this path enqueues min(iters, 32) rounds, each of which runs at least one iteration and all of
  * which together run at most `iters`. */
 size_t nnc_kmeans_prefix_bytes(int64_t n);
+/* Where the iterations of the fit ran so far (device counters, reset by nnc_kmeans_init): out8[0] iterations run by the
+ * one-workgroup loop, [1] launches of it that had work, [2] iterations in which centres changed places, [3] iterations it handed
+ * to the wide pair (a very long undecided stretch, a search that did not settle), [4] iterations the wide pair ran, [5..7]
+ * diagnostics.  Synchronises the stream. */
+int nnc_kmeans_loop_stats(void *ws, int32_t *out8, void *stream);
 int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_params *p, int64_t *prefix_dev, void *stream);
 
 /* centers_init_dev: k float32, un-centred (the reference's `space`).  Resets the state. */
@@ -440,7 +450,8 @@ typedef struct nnc_layer_params {
     int32_t bits;         /* 2**bits centroids (+ 1 for density) */
     int32_t mode;         /* NNC_INIT_LINEAR / NNC_INIT_DENSITY */
     int32_t want_values;  /* write cluster_centers_[labels_] to values_out */
-    int32_t reserved[2];
+    int32_t km_flags;     /* nnc_kmeans_params.flags of the fit (0, NNC_KM_TWO_LAUNCH or NNC_KM_LOOP) */
+    int32_t reserved;
 } nnc_layer_params;
 typedef struct nnc_layer_result {
     int32_t status, k, label_bytes, arith;

@@ -22,6 +22,8 @@ NNC_KMAX = 1040
 NNC_CHUNK = 8192
 FOLD_SUM, FOLD_MEAN, FOLD_STD = 0, 1, 2
 NNC_KM_TWO_LAUNCH = 1   # nnc_kmeans_params.flags: iterate launch by launch (include/nnc.h)
+NNC_KM_LOOP = 2         # ... inside one resident workgroup whatever K
+NNC_KM_LOOP_KMAX = 192  # up to here the library takes the loop by itself
 
 
 class NativeLibraryError(RuntimeError):
@@ -53,7 +55,7 @@ class KMeansStatus(ctypes.Structure):
 
 class LayerParams(ctypes.Structure):
     _fields_ = [("q", c_f32), ("prune", c_i32), ("std_smooth", c_i32), ("bits", c_i32), ("mode", c_i32), ("want_values", c_i32),
-                ("reserved", c_i32 * 2)]
+                ("km_flags", c_i32), ("reserved", c_i32)]
 
 
 class LayerResult(ctypes.Structure):
@@ -96,6 +98,7 @@ SIGNATURES = {
     "nnc_fix_shift": (c_i32, [c_f32, c_i64]),
     "nnc_kmeans_workspace_bytes": (c_size, [c_i32]),
     "nnc_kmeans_prefix_bytes": (c_size, [c_i64]),
+    "nnc_kmeans_loop_stats": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nnc_kmeans_prefix_build": (c_int, [c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
     "nnc_kmeans_init": (c_int, [c_void_p, c_size, ctypes.POINTER(KMeansParams), c_void_p, c_void_p]),
     "nnc_kmeans_set_centers": (c_int, [c_void_p, ctypes.POINTER(KMeansParams), c_void_p, c_int, c_void_p]),
@@ -169,6 +172,7 @@ DIAG_SIGNATURES = {
     "nnc_debug_set_trace": (c_int, [c_void_p]),
     "nnc_debug_clock": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
+    "nnc_debug_kl_trace": (c_int, [c_void_p, c_void_p]),
 }
 
 _lib = None

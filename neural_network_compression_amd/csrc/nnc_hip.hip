@@ -952,7 +952,9 @@ struct KmWs {
     // than float32 can tell apart, a search that did not settle): the k_bounds / k_finalize pair enqueued behind the loop "in case"
     // runs only then and clears it; kl_budget = iterations the launches of the current host call may still run
     int32_t wide, kl_budget;
-    float kl_hL[NNC_KMAX], kl_hR[NNC_KMAX]; // per boundary: the threshold its rank (hint_a) was found for, and the local density there (samples per unit)
+    unsigned long long kl_trace[24]; // diagnostics build: time per phase of k_lloyd (10 ns ticks), summed over the fit
+    int32_t kl_stats[8]; // [0] iterations the loop ran, [1] its launches, [2] of them with centres changing places, [3] iterations handed over, [4] iterations the wide pair ran
+    float kl_hL[2 * NNC_KMAX], kl_hR[2 * NNC_KMAX]; // per search (two a boundary: its ranks hint_a / hint_b): the threshold the rank was found for, the local density there (samples per unit)
     KmTab tab[2];
 };
 
@@ -1560,7 +1562,7 @@ __device__ float wave_pairwise_sum(F elem, int n, PwHeap *hp)
 #endif
 #define KM_PB NNC_PREFIX_BLOCK
 #define KM_PG 1024 // blocks per group of the two-level prefix
-#define KM_TILE 1024
+#define KM_TILE 2048
 #define KM_Q_VALID (1ull << 62)
 
 // a value every lane holds alike, moved to scalar registers (so that the control flow that depends on it is scalar)
@@ -2136,6 +2138,48 @@ __device__ __forceinline__ double km_rcp_up(double d)
     return (d > 1e-37 && d < 1e37) ? (double)r * (1.0 + 9.5367431640625e-07) : 1.0 / d;
 }
 
+// Between which x~ can scikit-learn's float32 comparison of the distances to two centres cp < cq go either way?  Outside the
+// interval returned here it cannot: below it d_p < d_q, above it d_q < d_p, strictly, in float32 as computed by
+//     d_j(x) = fl( C_j + fl(-2 * fl(x * c_j)) ),   C_j = fl(c_j * c_j)          (_k_means_lloyd.pyx:196-203)
+// Two bounds, both rigorous; the interval is their intersection.
+// (a) global: |d_j - (c_j^2 - 2 x c_j)| <= E = 2.5 * 2^-24 * (cm^2 + 2 xb cm) for every |x| <= xb (cm = max |c|), and the exact
+//     difference of the two distances is 2 delta (x - mid): decided once |x - mid| > E / delta.
+// (b) local, several times tighter where it matters (the dense middle of the data, where |x| is far below xb): the squares C_j are
+//     known float32 numbers, so take them as they are: D_j(x) = C_j - 2 x c_j crosses at x* = (C_q - C_p) / (2 delta) (the
+//     midpoint, moved by the rounding of the squares), D_p - D_q = 2 delta (x - x*), and with u = 2^-24
+//         |d_j - D_j| <= u (1 + u) 2 |x c_j| + u |D_j|                      (one rounding in the product, one in the sum)
+//         |D_j(x)| <= |D*| + 2 |x - x*| |c_j|,   D* = D_p(x*) = D_q(x*);    |x| <= |x*| + |x - x*|
+//     so with S = |c_p| + |c_q| the comparison is decided once
+//         |x - x*| (2 delta - (4 + 2u) u S) > u (2 |D*| + (2 + 2u) |x*| S)
+//     -- linear in |x - x*| on both sides, hence for every x beyond that distance, not only near it.  (Both sides get a hair of
+//     slack for the double arithmetic here and for products that underflow.)
+struct KmZone { double lo, hi; };
+__device__ __forceinline__ KmZone km_pair_zone(const double cp, const double cq, const double xb)
+{
+    const double U = 5.9604644775390625e-08; // 2^-24
+    const double delta = cq - cp;            // > 0: the callers pass distinct centres in value order
+    const double cm = fmax(fabs(cp), fabs(cq));
+    const double mid = 0.5 * (cp + cq);
+    const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
+    const double w0 = E * km_rcp_up(delta);
+    KmZone z;
+    z.lo = mid - w0; z.hi = mid + w0;
+    const double S = fabs(cp) + fabs(cq);
+    const double den = 2.0 * delta - 4.5 * U * S;
+    if (den > delta) { // (else the two centres are a few ulps apart: the global bound says all there is to say)
+        const float cpf = (float)cp, cqf = (float)cq;
+        const double Cp = (double)(cpf * cpf), Cq = (double)(cqf * cqf);
+        const double xs = (Cq - Cp) / (2.0 * delta);
+        const double Ds = fmax(fabs(Cp - 2.0 * xs * cp), fabs(Cq - 2.0 * xs * cq));
+        const double num = U * (2.0 * Ds + 2.0000005 * fabs(xs) * S) * 1.000001 + 1e-42;
+        const double w = (num / den) * 1.000001 + fabs(xs) * 4.5e-16;
+        z.lo = fmax(z.lo, xs - w); z.hi = fmin(z.hi, xs + w);
+    }
+    return z;
+}
+// how far the crossing point of a pair can lie from its midpoint at most (for the early exit of the loops over the pairs)
+__device__ __forceinline__ double km_pair_slack(const double delta, const double xb) { return 1.25e-7 * xb * xb * km_rcp_up(delta); }
+
 // NT threads: a fit with few centres runs it as a single wave (64) or four (256), for which the many barriers and
 // wave-to-wave hand-overs of the scans cost next to nothing; NT >= k is all it needs (k > 1024 takes two rounds of 1024).
 // WAVE (NT == 64 only): the body is run by ONE wave of a larger workgroup, so it may not use workgroup barriers; the
@@ -2179,6 +2223,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     const int spec_go = ws->spec_go;
     const int k = ws->p.k, Sft = ws->p.fix_shift, max_iter = ws->p.max_iter, glog2 = ws->glog2;
     const float tol_v = ws->p.tol, p_lo = ws->p.lo, p_hi = ws->p.hi, inv_f = ws->inv;
+    const long long n_tot = ws->p.n_total;
     const int ku0 = ws->tab[0].ku, ku1 = ws->tab[1].ku;
     int cur = ws->cur;
     if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) return false;
@@ -2451,6 +2496,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         const int rounds = (ku + NT - 1) / NT;
         int *wave_i = reinterpret_cast<int *>(wave_a);
         int carry_g = -2;
+        int wide_zone = 0;
         for (int rd = 0; rd < rounds; rd++) { // (the raw G_p / H_p go to gcell / hcell; the scans below run over them in place)
             const int p = rd * NT + tid;
             int gp = -2, hp_ = G + 1;
@@ -2460,27 +2506,22 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                 for (int q = p + 1; q < ku; q++) {
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
-                    if (mid >= right) break; // every later midpoint is larger still
                     const double delta = cq - cp;
-                    if (delta > 0.0) {
-                        const double cm = fmax(fabs(cp), fabs(cq));
-                        const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                        right = fmin(right, mid + E * km_rcp_up(delta));
-                    }
+                    if (mid - km_pair_slack(delta, xb) >= right) break; // every later pair's interval ends further up still
+                    if (delta > 0.0) right = fmin(right, km_pair_zone(cp, cq, xb).hi);
                 }
                 for (int q = p - 1; q >= 0; q--) {
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
-                    if (mid <= left) break;
                     const double delta = cp - cq;
-                    if (delta > 0.0) {
-                        const double cm = fmax(fabs(cp), fabs(cq));
-                        const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                        left = fmax(left, mid - E * km_rcp_up(delta));
-                    }
+                    if (mid + km_pair_slack(delta, xb) <= left) break;
+                    if (delta > 0.0) left = fmax(left, km_pair_zone(cq, cp, xb).lo);
                 }
                 tab->zl[p] = left; tab->zr[p] = right;
                 ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
+                // a zone wide enough to hold thousands of samples (two centres float32 can hardly tell apart): the coming pass will
+                // publish a long undecided stretch, and every wave of it had better look at the tile queue when its own work is done
+                if (p > 0 && p + 1 < ku && (right - left) * (double)n_tot * 4.0 > (double)KM_TILE * ((double)p_hi - (double)p_lo)) wide_zone = 1;
                 gp = G - 1; hp_ = 0;
                 if (inv > 0.0 && !lazy) {
                     const double qa = (right - lo) / ra; // may be +-inf
@@ -2496,6 +2537,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             }
             if (p < ku) { gcell[p] = gp; hcell[p] = hp_; }
         }
+        if (FIN_OR(wide_zone) && tid == 0) ws->help_hint = 1;
         FIN_SYNC();
         FSTAMP(11);
         if (!lazy) { // (the rank-boundary iterations do not use the cell side of the zones: k_cells works it out on demand)
@@ -2617,7 +2659,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
     }
     if (cond && fin_asked) { // the iteration k_lloyd handed over has been run (or has paused): the loop may go on
         __syncthreads();
-        if (tid == 0) { ws->wide = 0; ws->kl_budget = ws->kl_budget - 1; }
+        if (tid == 0) { ws->wide = 0; ws->kl_budget = ws->kl_budget - 1; ws->kl_stats[4] += 1; }
     }
     if (host_st) {
         __syncthreads();
@@ -2833,8 +2875,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
-    for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->kl_hL[i] = 0.0f; ws->kl_hR[i] = 0.0f; }
+    for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->kl_hL[i] = 0.0f; ws->kl_hR[i] = 0.0f; }
     if (tid == 0) { ws->q_n = 0; ws->help_hint = 0; ws->help_pad = 0; ws->wide = 0; ws->kl_budget = 0; }
+    if (tid < 8) ws->kl_stats[tid] = 0;
+    if (tid < 24) ws->kl_trace[tid] = 0ull;
 }
 
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
@@ -2909,6 +2953,13 @@ __global__ void k_debug_clock(int iters, float *out)
         out[2 * blockIdx.x + 1] = (float)((double)(r1 - r0) * 0.01);              // us
     }
     if (a + b == 123.456f) out[0] = a;
+}
+
+extern "C" int nnc_debug_kl_trace(void *ws, unsigned long long *out8)
+{
+    if (!ws || !out8) return fail(NNC_EINVAL, "nnc_debug_kl_trace: null pointer");
+    HIPCHK(hipMemcpy(out8, reinterpret_cast<KmWs *>(ws)->kl_trace, 24 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return NNC_OK;
 }
 
 extern "C" int nnc_debug_set_trace(unsigned long long *buf_dev)
@@ -3003,7 +3054,9 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
 // ---- the one-workgroup loop (nnc_lloyd.hpp) and, behind it, the wide pair in case it hands an iteration over --------------------
 static bool km_lloyd_ok(const nnc_kmeans_params *p, const float *x)
 {
-    return p->prefix_dev && p->n > 0 && p->n == p->n_total && !(p->flags & NNC_KM_TWO_LAUNCH) && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (!(p->prefix_dev && p->n > 0 && p->n == p->n_total && (reinterpret_cast<uintptr_t>(x) & 15) == 0)) return false;
+    if (p->flags & NNC_KM_TWO_LAUNCH) return false;
+    return (p->flags & NNC_KM_LOOP) || p->k <= NNC_KM_LOOP_KMAX; // (beyond that one compute unit's instruction rate is the bound: include/nnc.h)
 }
 
 static int km_launch_lloyd(const float *xs, KmWs *w, const nnc_kmeans_params *p, int budget_set, void *stream)
@@ -3083,6 +3136,17 @@ extern "C" int nnc_kmeans_finalize(void *ws, int resume, void *stream)
 {
     if (!ws) return fail(NNC_EINVAL, "nnc_kmeans_finalize: null workspace");
     return km_launch_finalize(reinterpret_cast<KmWs *>(ws), nullptr, FIN_FROM_PARTIALS, resume ? 1 : 0, stream);
+}
+
+// Where the iterations of the fit ran so far (device counters, reset by nnc_kmeans_init): out[0] iterations run by the one-workgroup
+// loop, out[1] launches of it that had work, out[2] iterations in which centres changed places, out[3] iterations it handed to the
+// wide pair (a very long undecided stretch, a search that did not settle), out[4] iterations the wide pair ran.  Synchronises the stream.
+extern "C" int nnc_kmeans_loop_stats(void *ws, int32_t *out8, void *stream)
+{
+    if (!ws || !out8) return fail(NNC_EINVAL, "nnc_kmeans_loop_stats: null pointer");
+    HIPCHK(hipMemcpyAsync(out8, reinterpret_cast<KmWs *>(ws)->kl_stats, 8 * sizeof(int32_t), hipMemcpyDeviceToHost, S(stream)));
+    HIPCHK(hipStreamSynchronize(S(stream)));
+    return NNC_OK;
 }
 
 extern "C" int nnc_kmeans_iterate(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *stream)

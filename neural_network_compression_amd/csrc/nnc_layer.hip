@@ -329,7 +329,7 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         const volatile float lo = xmin - mean, hi = xmax - mean; // exact range of the centred data
         p.n = n; p.n_total = n; p.k = k; p.max_iter = 300;
         p.fix_shift = nnc_fix_shift(std::max(std::fabs((float)lo), std::fabs((float)hi)), n);
-        p.grid_log2 = 0; p.replicas_log2 = -1; p.flags = 0;
+        p.grid_log2 = 0; p.replicas_log2 = -1; p.flags = lp->km_flags & (NNC_KM_TWO_LAUNCH | NNC_KM_LOOP);
         p.x_mean = mean; p.tol = tol; p.lo = lo; p.hi = hi;
         // ---- initial centroids (utility.py:206-226)
         if (lp->mode == NNC_INIT_LINEAR) {

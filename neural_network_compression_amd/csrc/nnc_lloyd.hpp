@@ -1,36 +1,49 @@
 // nnc_lloyd.hpp -- the Lloyd loop of one fit inside ONE workgroup (textually included by nnc_hip.hip, which owns KmWs and the helpers).
 //
 // The two-launch iteration (k_bounds: one wave per cluster boundary, sums by global atomics; k_finalize: one workgroup) spends
-// its time in launch boundaries and dependent round trips to memory, not in work: at K = 257 on 25 M weights an iteration reads
-// about 3 MB and takes 24 us.  Here one resident workgroup runs iteration after iteration until the fit stops, pauses for an
-// empty cluster or meets something it hands to the wide path:
-//   * everything K-sized lives in LDS: centres, zone ends, per-cluster sums and counts, the previous label counts, and for every
-//     boundary where it was found last time (rank, threshold, local density);
-//   * a boundary is looked up by a group of EIGHT lanes.  One probe = the 64 samples (256 B, two lines) around the predicted rank
-//     plus the 8-byte fine prefix in front of them (nnc_kmeans_prefix_build).  The prediction is a Newton step on the rank
-//     function (rank moves by density x threshold shift); from the second Lloyd iteration on it lands in the right block almost
-//     always, so an iteration costs about three cache lines per boundary -- which matters more than latency here: one CU takes in
-//     a few hundred lines per microsecond.  A miss is followed by another Newton step from the block just read, or by a nine-way
-//     split of the bracket (eight single-sample probes), so the search is logarithmic whatever the data look like;
-//   * the block that holds the boundary also gives the prefix sum at the rank (fine prefix + the images below the cut) and the
-//     few undecided samples above it, which are labelled with scikit-learn's exact float32 expression between the two centres;
-//   * the finalize step (average, shift, NumPy's pairwise sum, tolerance test, centre order, zones) runs on the same LDS arrays.
+// its time in launch boundaries and dependent round trips to memory, not in work.  Here one resident workgroup runs iteration after
+// iteration until the fit stops, pauses for an empty cluster or meets something it hands to the wide path:
+//   * everything K-sized lives in LDS: centres, zone ends (as float32 thresholds), per-cluster sums and counts, the previous label
+//     counts, and for each of the 2 (K - 1) rank searches where it ended last time (rank, threshold, density there);
+//   * pass 1, kl_search: the ranks a_j = #{x~ < L_j} and b_j = #{x~ <= U_j} of every boundary, each by a group of EIGHT lanes.  A probe
+//     = the 128 samples around the predicted rank + the two 8-byte fine prefixes in front of them (nnc_kmeans_prefix_build); the
+//     prediction is a Newton step on the rank function (rank moves by density x threshold shift, the density measured over the
+//     last move).  A second miss goes to a bracketed search (Newton from the block just read, else a nine-way split of the
+//     bracket: eight single-sample probes), logarithmic whatever the data look like.  The block that holds the rank also gives the
+//     prefix sum there (fine prefix + the images in front of the rank inside the block);
+//   * pass 2, kl_label: the samples float32 cannot place from the zones alone, [max(a_j, b_{j-1}), b_j), cut into chunks dealt round
+//     robin to the groups and labelled with scikit-learn's exact float32 expression -- between two centres, or against all of
+//     j .. phi_j where three or more centres sit within rounding distance of each other;
+//   * the finish step (sums from prefix differences, average, shift, NumPy's pairwise sum, tolerance test, centre order, zones) on the
+//     same LDS arrays: six barriers when nothing unusual happens (kl_finish_fast), the general step otherwise (kl_finish).
 // What it does not do itself: empty clusters (status.paused, as k_finalize reports them: the relocation chain takes over) and
-// iterations in which three or more centres sit within float32 rounding of each other or an undecided stretch is long
-// (ws->wide: the k_bounds / k_finalize pair enqueued behind every launch of the loop runs exactly then).
+// iterations with more than a million undecided samples (two centres float32 can hardly tell apart) or a search that does not
+// settle (ws->wide: the k_bounds / k_finalize pair enqueued behind every launch of the loop runs exactly then).
 // Same integers, same float32 operations as the two-launch form: the trajectory is bit-identical (tests/test_gpu_lloyd.py).
+// Measured (tools/sweep_loop_vs_two.py, 0.1 M - 25 M weights): 0.46 - 0.8 of the launch-per-iteration time up to K = 65, about the
+// same at K = 129, 1.0 - 1.2 of it at K = 257 -- sixteen waves on one compute unit issue an instruction every eight cycles each, and
+// 512 searches of a few hundred instructions are then the bound -- so the library takes the loop up to NNC_KM_LOOP_KMAX centres.
 //
 // Reference: the loop of sklearn/cluster/_kmeans.py:_kmeans_single_lloyd (624-752), reached from utility.py:237-238.
 
+struct KlDiag { unsigned long long ph[16], last, sp[8], slast; };
+#ifdef NNC_DIAG
+#define KLSTAMP(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); dg->ph[slot] += now_ - dg->last; dg->last = now_; } } while (0)
+#define KLSUB(slot) do { if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); dg->sp[slot] += now_ - dg->slast; dg->slast = now_; } } while (0)
+#else
+#define KLSTAMP(slot) do { } while (0)
+#define KLSUB(slot) do { } while (0)
+#endif
 #define KL_MAXR 24      // probes per boundary before it is handed to the wide path (never reached on monotone data: <= 20)
-#define KL_TAIL_MAX 256 // undecided samples per boundary the group labels itself
+#define KL_TAIL_MAX 2048 // samples between the ranks a and b a group of eight lanes goes through itself
 
 struct KlHeap { int start[64]; int len[64]; float val[64]; };
 struct KlHead {
-    int ku, slow, crowd, n_empty, depth, pad0, pad1, pad2;
+    int ku, slow, nch, n_empty, depth, pad0, pad1, pad2;
     float tot;
+    int f_empty, f_diff, f_reorder;   // votes of the fast finish step (set by any wave, read behind a barrier, cleared by thread 0)
     int wave_i[16];
-    int pad3[3];
+    double wmax[16], wmin[16];        // per wave: the largest zone end from below, the smallest from above
     KlHeap heap;
 };
 static_assert(sizeof(KlHead) % 16 == 0, "the arrays behind the header are 16-byte aligned");
@@ -38,11 +51,11 @@ static_assert(sizeof(KlHead) % 16 == 0, "the arrays behind the header are 16-byt
 struct KlArr {
     double *Lb, *Ub;                                                   // per boundary j: L_j, U_j (per centre while the zones are being made: zl, zr)
     long long *sum_s, *cnt_s, *A, *B, *PA, *PB, *prevc, *hint;          // A/B double as the per-cluster sums / counts in original index order
-    float *hL, *hR, *cs, *csq, *cnew, *cold, *sq, *call;
-    uint16_t *so, *perm;
+    float *hL, *hR, *cs, *csq, *cnew, *cold, *sq, *call, *Lf, *Uf;         // Lf / Uf: L_j rounded up, U_j rounded down to float32
+    uint16_t *so, *perm, *phi, *qj;                                      // phi[j]: the highest centre that can still win below U_j; qj: the labelling chunks' boundaries
 };
 
-static size_t kl_lds_bytes(int kc) { return sizeof(KlHead) + (size_t)kc * (2 * 8 + 8 * 8 + 8 * 4 + 2 * 2); }
+static size_t kl_lds_bytes(int kc) { return sizeof(KlHead) + (size_t)kc * (2 * 8 + 9 * 8 + 12 * 4 + 3 * 2) + 4096 * 2; }
 
 __device__ __forceinline__ void kl_carve(unsigned char *smem, int kc, KlHead **hd, KlArr *L)
 {
@@ -53,17 +66,41 @@ __device__ __forceinline__ void kl_carve(unsigned char *smem, int kc, KlHead **h
     L->sum_s = reinterpret_cast<long long *>(take((size_t)kc * 8)); L->cnt_s = reinterpret_cast<long long *>(take((size_t)kc * 8));
     L->A = reinterpret_cast<long long *>(take((size_t)kc * 8)); L->B = reinterpret_cast<long long *>(take((size_t)kc * 8));
     L->PA = reinterpret_cast<long long *>(take((size_t)kc * 8)); L->PB = reinterpret_cast<long long *>(take((size_t)kc * 8));
-    L->prevc = reinterpret_cast<long long *>(take((size_t)kc * 8)); L->hint = reinterpret_cast<long long *>(take((size_t)kc * 8));
-    L->hL = reinterpret_cast<float *>(take((size_t)kc * 4)); L->hR = reinterpret_cast<float *>(take((size_t)kc * 4));
+    L->prevc = reinterpret_cast<long long *>(take((size_t)kc * 8)); L->hint = reinterpret_cast<long long *>(take((size_t)kc * 16)); // (two searches per boundary)
+    L->hL = reinterpret_cast<float *>(take((size_t)kc * 8)); L->hR = reinterpret_cast<float *>(take((size_t)kc * 8));
     L->cs = reinterpret_cast<float *>(take((size_t)kc * 4)); L->csq = reinterpret_cast<float *>(take((size_t)kc * 4));
     L->cnew = reinterpret_cast<float *>(take((size_t)kc * 4)); L->cold = reinterpret_cast<float *>(take((size_t)kc * 4));
     L->sq = reinterpret_cast<float *>(take((size_t)kc * 4)); L->call = reinterpret_cast<float *>(take((size_t)kc * 4));
+    L->Lf = reinterpret_cast<float *>(take((size_t)kc * 4)); L->Uf = reinterpret_cast<float *>(take((size_t)kc * 4));
     L->so = reinterpret_cast<uint16_t *>(take((size_t)kc * 2)); L->perm = reinterpret_cast<uint16_t *>(take((size_t)kc * 2));
+    L->phi = reinterpret_cast<uint16_t *>(take((size_t)kc * 2));
+    L->qj = reinterpret_cast<uint16_t *>(take((size_t)4096 * 2));
 }
 
-// sums over a group of eight lanes (every lane of the group gets the total)
-__device__ __forceinline__ int grp8_sum_i(int v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
-__device__ __forceinline__ long long grp8_sum_ll(long long v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+// Sums / minimum over a group of eight lanes (every lane of the group gets the result) by DPP: two quad permutes and a mirror
+// inside the half row -- no LDS crossbar, one VALU instruction each.  Call with the whole wave active.
+#define KL_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define KL_QP_XOR1 0xB1 // quad_perm [1,0,3,2]
+#define KL_QP_XOR2 0x4E // quad_perm [2,3,0,1]
+#define KL_HALF_MIRROR 0x141
+__device__ __forceinline__ int grp8_sum_i(int v)
+{
+    v += KL_DPP_I(v, KL_QP_XOR1); v += KL_DPP_I(v, KL_QP_XOR2); v += KL_DPP_I(v, KL_HALF_MIRROR);
+    return v;
+}
+__device__ __forceinline__ int grp8_min_i(int v)
+{
+    v = min(v, KL_DPP_I(v, KL_QP_XOR1)); v = min(v, KL_DPP_I(v, KL_QP_XOR2)); v = min(v, KL_DPP_I(v, KL_HALF_MIRROR));
+    return v;
+}
+__device__ __forceinline__ long long grp8_sum_ll(long long v)
+{
+#define KL_STEP_LL(ctrl) do { const int lo_ = KL_DPP_I((int)(unsigned)(v & 0xFFFFFFFFll), ctrl), hi_ = KL_DPP_I((int)(v >> 32), ctrl); \
+        v += (long long)(((unsigned long long)(unsigned)hi_ << 32) | (unsigned)lo_); } while (0)
+    KL_STEP_LL(KL_QP_XOR1); KL_STEP_LL(KL_QP_XOR2); KL_STEP_LL(KL_HALF_MIRROR);
+#undef KL_STEP_LL
+    return v;
+}
 
 // ---- NumPy's pairwise float32 sum of e[0 .. n) (n <= 2048), the split tree made once per launch -------------------------------
 __device__ void kl_heap_build(KlHead *hd, int n) // by the first wave; the caller puts a workgroup barrier behind it
@@ -140,7 +177,6 @@ __device__ __forceinline__ void kl_pairwise(KlHead *hd, const float *e, int n) /
 
 // ---- zone ends per centre (zl in Lb[], zr in Ub[]) -> thresholds per boundary, and whether any three centres crowd --------------
 //   U_j = max over q <= j of zr[q] (above it no centre up to j can win), L_j = min over q > j of zl[q] (below it none above j can).
-//   Boundary j is plain when only the centres j and j + 1 can win between L_j and U_j:  L_{j+1} > U_j.
 template <int NT>
 __device__ __forceinline__ void kl_derive(KlHead *hd, const KlArr &L, int ku)
 {
@@ -176,10 +212,19 @@ __device__ __forceinline__ void kl_derive(KlHead *hd, const KlArr &L, int ku)
 #pragma unroll
     for (int r = 0; r < 2; r++) { const int q = tid + r * NT; if (q < ku) L.Lb[q] = t[r]; }
     __syncthreads();
-    int crowd = 0;
-    for (int j = tid; j + 2 < ku; j += NT) crowd |= (L.Lb[j + 1] <= L.Ub[j]) ? 1 : 0;
-    const int any = __syncthreads_or(crowd);
-    if (tid == 0) hd->crowd = any;
+    // phi_j = max{q : zl[q] <= U_j}: the candidates of the samples boundary j cannot decide from the zones are the centres j .. phi_j
+    // (j + 1 unless centres crowd).  With the running minimum in place: the largest q whose L_{q-1} is still <= U_j.
+    for (int j = tid; j + 1 < ku; j += NT) {
+        int q = j + 1;
+        const double u = L.Ub[j], l = L.Lb[j];
+        while (q + 1 < ku && L.Lb[q] <= u) q++;
+        L.phi[j] = (uint16_t)q;
+        // the thresholds as float32: the smallest one >= L_j, the largest one <= U_j
+        float lf = (float)l, uf = (float)u;
+        if ((double)lf < l) lf = nextafterf(lf, INFINITY);
+        if ((double)uf > u) uf = nextafterf(uf, -INFINITY);
+        L.Lf[j] = lf; L.Uf[j] = uf;
+    }
     __syncthreads();
 }
 
@@ -187,7 +232,7 @@ __device__ __forceinline__ void kl_derive(KlHead *hd, const KlArr &L, int ku)
 // (perm[] holds the order of the previous iteration; `fresh`: it holds nothing yet)
 template <int NT>
 __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const int k, const int cur, const bool fresh,
-                                          const float p_lo, const float p_hi)
+                                          const float p_lo, const float p_hi, KlDiag *dg)
 {
     const int tid = threadIdx.x;
     KmTab *tab = &ws->tab[cur];
@@ -230,6 +275,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
         }
         __syncthreads();
     }
+    KLSTAMP(8); // order
     // equal centres: the first one (lowest original index) takes every tie, the others never win: distinct values only
     int ku = 0;
     {
@@ -266,8 +312,8 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
         ws->bnd.orig[p] = L.so[p];
     }
     if (tid == 0) { tab->ku = ku; ws->ku_cur = ku; ws->bnd.ku = ku; tab->n_ovf = 0; ws->cells_pending = 0; hd->ku = ku; }
+    KLSTAMP(9); // distinct + tables
     // zone of every centre: the x-interval on which it can be the float32 arg-min (km_finalize_body's rule and error bound)
-    const double U = 5.9604644775390625e-08; // 2^-24
     const double xb = fmax(fabs((double)p_lo), fabs((double)p_hi));
     for (int p = tid; p < ku; p += NT) {
         const double cp = (double)L.cs[p];
@@ -275,85 +321,150 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
         for (int q = p + 1; q < ku; q++) {
             const double cq = (double)L.cs[q];
             const double mid = 0.5 * (cp + cq);
-            if (mid >= right) break; // every later midpoint is larger still
             const double delta = cq - cp;
-            if (delta > 0.0) {
-                const double cm = fmax(fabs(cp), fabs(cq));
-                const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                right = fmin(right, mid + E * km_rcp_up(delta));
-            }
+            if (mid - km_pair_slack(delta, xb) >= right) break; // every later pair's interval ends further up still
+            if (delta > 0.0) right = fmin(right, km_pair_zone(cp, cq, xb).hi);
         }
         for (int q = p - 1; q >= 0; q--) {
             const double cq = (double)L.cs[q];
             const double mid = 0.5 * (cp + cq);
-            if (mid <= left) break;
             const double delta = cp - cq;
-            if (delta > 0.0) {
-                const double cm = fmax(fabs(cp), fabs(cq));
-                const double E = 2.5 * U * (cm * cm + 2.0 * xb * cm) + 1e-42;
-                left = fmax(left, mid - E * km_rcp_up(delta));
-            }
+            if (mid + km_pair_slack(delta, xb) <= left) break;
+            if (delta > 0.0) left = fmax(left, km_pair_zone(cq, cp, xb).lo);
         }
         L.Lb[p] = left; L.Ub[p] = right;
         tab->zl[p] = left; tab->zr[p] = right;
         ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
     }
     __syncthreads();
+    KLSTAMP(10); // zones
     kl_derive<NT>(hd, L, ku);
+    KLSTAMP(11); // thresholds, candidate ranges
 }
 
 // ---- the boundaries of one iteration ---------------------------------------------------------------------------------------------
-// Group g (eight lanes) takes the boundaries g, g + NT/8, ...  For boundary j (between the distinct centres j and j + 1, value order):
-//   a = #{x~ < L_j}, b = #{x~ <= U_j}, the prefix sums at both ranks, and the samples [a, b) labelled and added to the sums.
-// Results: A, PA, B, PB; the sums of the undecided samples go to sum_s / cnt_s by LDS atomics.
-template <int NT>
-__device__ __forceinline__ void kl_boundaries(const float *__restrict__ xs, const long long n, const long long *__restrict__ pf, const long long total,
-                                               const float mean, const int Sft, const int ku, KlHead *hd, const KlArr &L)
+// Pass 1 (kl_search).  Group g (eight lanes) takes the boundaries g, g + NT/8, ...  For boundary j (between the distinct centres j
+// and j + 1, value order) it finds the two ranks a = #{x~ < L_j} and b = #{x~ <= U_j} and the prefix sums at both (fine prefix of
+// the block that holds the rank + the images in front of it inside the block): A, PA, B, PB.  Usually one probe gives all four.
+// Pass 2 (kl_label).  The samples float32 cannot place from the zones alone are [max(a_j, b_{j-1}), b_j) for every j: cut into chunks of
+// KL_CHUNK samples, dealt round robin to the groups (so one long stretch does not hold up the workgroup and nothing is looked at
+// twice), labelled with scikit-learn's exact float32 expression -- between the centres j and j + 1 (sums in registers), or, where
+// three or more centres sit within rounding distance of each other, against all of j .. phi_j (first minimum, ties to the lowest
+// original index) -- and added to sum_s / cnt_s by LDS atomics.
+// The thresholds are float32 here (L_j rounded up, U_j rounded down): for a float32 x~, x~ < L_j <=> x~ < ceil32(L_j) and
+// x~ <= U_j <=> x~ <= floor32(U_j), so the comparisons are the double ones at a quarter of the instructions.
+template <int NT, typename IDX>
+__device__ __forceinline__ void kl_search(const float *__restrict__ xs, const long long n_, const long long *__restrict__ pf, const long long total,
+                                          const float mean, const int Sft, const int ku, KlHead *hd, const KlArr &L, KlDiag *dg)
 {
+    // 2 (ku - 1) independent searches "how many samples are at or below T": search 2j for a_j (T = the float32 below L_j, since
+    // x~ < L_j <=> x~ <= pred32(L_j)), search 2j + 1 for b_j (T = U_j).  Each has its own hint (rank, threshold, density there).
     const int tid = threadIdx.x, g = tid >> 3, gl = tid & 7, lane = tid & 63, g0 = lane & ~7;
-    const int nb = ku - 1;
+    const IDX n = (IDX)n_; // (IDX = int while the ranks fit)
+    const int ns = 2 * (ku - 1);
     const float4 *__restrict__ x4 = reinterpret_cast<const float4 *>(xs);
-    for (int j0 = 0; j0 < nb; j0 += NT / 8) {
-        const int j = j0 + g;
-        const bool have = j < nb;
-        const int jj = have ? j : 0;
-        const double Lt = L.Lb[jj], Ut = L.Ub[jj];
-        const float c0 = L.cs[jj], q0 = L.csq[jj], c1 = L.cs[jj + 1], q1 = L.csq[jj + 1];
-        const bool tie1 = L.so[jj + 1] < L.so[jj];
-        long long lo = 0, hi = n;  // the rank a lies in [lo, hi]: samples below lo are < L_j, samples from hi on are not
-        int st = have ? 0 : 2;     // 0 searching, 1 labelling on into the next block, 2 done, 3 handed over
+    for (int s0 = 0; s0 < ns; s0 += NT / 8) {
+        KLSUB(0); // (between the sub-passes)
+        const int sx = s0 + g;
+        const bool have = sx < ns;
+        const int si = have ? sx : 0, jj = si >> 1;
+        const float T = (si & 1) ? L.Uf[jj] : nextafterf(L.Lf[jj], -INFINITY);
+        IDX lo = 0, hi = n;  // the rank lies in [lo, hi]: samples below lo are <= T, samples from hi on are not
+        int st = have ? 0 : 2;     // 0 searching, 2 found, 3 handed over
         int mode = 1;              // 0: read the block that holds `pred`; 1: nine-way split of the bracket
-        long long pred = 0;
+        IDX pred = 0;
         {
-            const long long h = L.hint[jj];
+            const long long h = L.hint[si];
             if (h >= 0 && h <= n) {
-                const float r = L.hR[jj];
-                double pr = (double)h;
-                if (r > 0.0f && r < 3.0e38f) pr += ((double)(float)Lt - (double)L.hL[jj]) * (double)r; // Newton step on the rank function
-                if (!(pr >= 0.0)) pr = 0.0;
-                if (!(pr <= (double)(n - 1))) pr = (double)(n - 1);
-                pred = (long long)pr; mode = 0;
+                const float r = L.hR[si];
+                float shift = 0.0f;
+                if (r > 0.0f && r < 3.0e38f) shift = (T - L.hL[si]) * r; // Newton step on the rank function
+                if (!(shift > -1.0e9f && shift < 1.0e9f)) shift = 0.0f;
+                long long pr = h + (long long)shift;
+                if (pr < 0) pr = 0;
+                if (pr > n_ - 1) pr = n_ - 1;
+                pred = (IDX)pr; mode = 0;
             }
         }
-        long long a = 0, b = 0, pfa = 0;           // results (group-uniform)
-        long long s0 = 0, s1 = 0, pa_part = 0;     // this lane's share
-        int n0 = 0, n1 = 0, und = 0, misses = 0;
+        IDX rank = 0;
+        long long pfr = 0, part = 0;
+        int misses = 0;
         float rho_found = 0.0f;
+        KLSUB(1); // set-up of the searches
+        // ---- the steady state first: the block the hint points at (two tries, the second a Newton step from the first block).  No
+        // bracket bookkeeping, a third of the instructions of the general loop below, which only the searches that miss twice
+        // (and the first iteration, without hints) go through.
+        for (int fr = 0; fr < 2; fr++) {
+            // two blocks: the one that holds rank pred - 32 and the next (the prediction sits at least 32 samples from either end)
+            const IDX b0 = (pred > 32 ? pred - 32 : 0) >> 6;
+            const IDX base = b0 << 6;
+            const bool go = st == 0 && mode == 0 && base + 2 * KL_BLK <= n; // (two full blocks)
+            if (!__any(go)) break;
+            float x[16];
+            long long pfx0 = 0, pfx1 = 0;
+            if (go) {
+                const float4 v0 = x4[(base >> 2) + gl], v1 = x4[(base >> 2) + 8 + gl], v2 = x4[(base >> 2) + 16 + gl], v3 = x4[(base >> 2) + 24 + gl];
+                x[0] = v0.x - mean; x[1] = v0.y - mean; x[2] = v0.z - mean; x[3] = v0.w - mean;
+                x[4] = v1.x - mean; x[5] = v1.y - mean; x[6] = v1.z - mean; x[7] = v1.w - mean;
+                x[8] = v2.x - mean; x[9] = v2.y - mean; x[10] = v2.z - mean; x[11] = v2.w - mean;
+                x[12] = v3.x - mean; x[13] = v3.y - mean; x[14] = v3.z - mean; x[15] = v3.w - mean;
+                pfx0 = pf[b0]; pfx1 = pf[b0 + 1];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; t++) x[t] = 0.0f;
+            }
+            int cnt = 0;
+#pragma unroll
+            for (int t = 0; t < 16; t++) cnt += (x[t] <= T) ? 1 : 0;
+            const int cT = grp8_sum_i(cnt); // 0 .. 128
+            const bool hit = go && ((cT > 0 || base == 0) && cT < 2 * KL_BLK);
+            if (hit) { // the rank lies inside these two blocks: the fine prefix of its own block + the images in front of it there
+                rank = base + cT; st = 2;
+                const int first = cT >= KL_BLK ? KL_BLK : 0;
+                pfr = cT >= KL_BLK ? pfx1 : pfx0;
+#pragma unroll
+                for (int t = 0; t < 16; t++) { // sample t of this lane is number 32 (t / 4) + 4 gl + t % 4 of the 128
+                    const int idx = 32 * (t >> 2) + 4 * gl + (t & 3);
+                    if (idx >= first && idx < cT) part += fix_f32(x[t], Sft);
+                }
+            }
+            const bool miss = go && !hit;
+            if (__any(hit | miss)) {
+                const float fa = __shfl(x[0], g0), fb = __shfl(x[15], g0 + 7);
+                const float rho = (fb > fa) ? 127.0f / (fb - fa) : 0.0f;
+                if (hit) rho_found = rho;
+                if (miss) {
+                    if (cT == 0) { if (base < hi) hi = base; } else { if (base + 2 * KL_BLK > lo) lo = base + 2 * KL_BLK; }
+                    misses++;
+                    mode = 1;
+                    if (rho > 0.0f) {
+                        const float sh = (cT == 0) ? (T - fa) * rho : 127.0f + (T - fb) * rho;
+                        if (sh > -1.0e9f && sh < 1.0e9f) {
+                            const long long pr = (long long)base + (long long)sh;
+                            if (pr >= (long long)lo && pr < (long long)hi) { mode = 0; pred = (IDX)pr; }
+                        }
+                    }
+                    if (hi - lo <= KL_BLK) { mode = 0; pred = lo; }
+                }
+            }
+        }
+        KLSUB(2); // the lean probes
         for (int round = 0; round < KL_MAXR; round++) {
-            if (st == 0 && lo == hi && lo >= n) { a = n; b = n; pfa = total; st = 2; } // every sample is below L_j
-            const bool blockmode = (st == 1) || (st == 0 && mode == 0);
-            const bool scanmode = (st == 0 && mode == 1);
+            if (!__any(st == 0)) break;
+            if (st == 0 && lo == hi && lo >= n) { rank = n; pfr = total; st = 2; } // every sample is at or below T
+            const bool blockmode = (st == 0 && mode == 0), scanmode = (st == 0 && mode == 1);
             float x[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) x[t] = 0.0f;
-            long long base = 0, pfx = 0, r_i = 0;
+            IDX base = 0, w = 0;
+            long long pfx = 0;
             int len = 0;
             float sv = 0.0f;
             if (blockmode) {
-                if (st == 0 && lo == hi) pred = lo; // the bracket is closed: the block that holds rank a
+                if (lo == hi) pred = lo; // the bracket is closed: the block that holds the rank
                 if (pred > n - 1) pred = n - 1;
                 if (pred < 0) pred = 0;
-                const long long blk = pred >> 6;
+                const IDX blk = pred >> 6;
                 base = blk << 6;
                 len = (int)((n - base) < KL_BLK ? (n - base) : KL_BLK);
                 if (len == KL_BLK) {
@@ -365,108 +476,177 @@ __device__ __forceinline__ void kl_boundaries(const float *__restrict__ xs, cons
                 }
                 pfx = pf[blk];
             } else if (scanmode) {
-                const long long w = hi - lo; // >= 1
-                r_i = lo + (w * (gl + 1)) / 9; // lo <= r_i < hi, non-decreasing over the lanes
-                sv = xs[r_i];
+                w = hi - lo; // >= 1
+                sv = xs[lo + (IDX)(((long long)w * (gl + 1)) / 9)]; // probes lo <= r_1 <= ... <= r_8 < hi
             }
-            // ---- counts of the block (below L_j: low byte; at or below U_j: next byte) or of the eight probes
             int cnt = 0;
             if (blockmode) {
 #pragma unroll
                 for (int t = 0; t < 8; t++) {
                     const int idx = (t < 4) ? 4 * gl + t : 32 + 4 * gl + (t - 4);
-                    const double xd = (double)(x[t] - mean);
-                    const bool valid = idx < len;
-                    cnt += (valid && xd < Lt) ? 1 : 0;
-                    cnt += (valid && xd <= Ut) ? 256 : 0;
+                    x[t] = x[t] - mean;
+                    cnt += (idx < len && x[t] <= T) ? 1 : 0;
                 }
-            } else if (scanmode) cnt = ((double)(sv - mean) < Lt) ? 1 : 0;
-            cnt = grp8_sum_i(cnt);
-            const int cL = cnt & 0xFF, cE = cnt >> 8;
+            } else if (scanmode) { sv = sv - mean; cnt = (sv <= T) ? 1 : 0; }
+            const int cT = grp8_sum_i(cnt);
             // first / last sample of the block, or the two probes either side of the cut
-            const int srcA = blockmode ? g0 : g0 + (cL > 0 ? cL - 1 : 0);
-            const int srcB = blockmode ? g0 + 7 : g0 + (cL < 8 ? cL : 7);
-            const float mine_a = blockmode ? (x[0] - mean) : (sv - mean), mine_b = blockmode ? (x[7] - mean) : (sv - mean);
-            const float fa = __shfl(mine_a, srcA), fb = __shfl(mine_b, srcB);
-            const long long ra = __shfl(r_i, srcA), rb = __shfl(r_i, srcB);
-            if (blockmode && st < 2) {
-                int ca = 0;        // samples of this block that are certainly below the boundary
-                bool label = false;
-                if (st == 1) label = true;
-                else {
-                    bool found = false;
-                    if (lo == hi) found = true;
-                    else if (cL == 0 && base > lo) hi = base;
-                    else if (cL == len && base + len < hi) lo = base + len;
-                    else { found = true; lo = hi = base + cL; }
-                    if (found) {
-                        ca = (int)(lo - base);
-                        if (ca < len) { // the block holds rank a: prefix sum there, and the labelling starts
-                            a = lo; pfa = pfx; label = true;
-                            rho_found = (len == KL_BLK && fb > fa) ? 63.0f / (fb - fa) : 0.0f;
+            const int srcA = blockmode ? g0 : g0 + (cT > 0 ? cT - 1 : 0);
+            const int srcB = blockmode ? g0 + 7 : g0 + (cT < 8 ? cT : 7);
+            const float fa = __shfl(blockmode ? x[0] : sv, srcA), fb = __shfl(blockmode ? x[7] : sv, srcB);
+            if (blockmode) {
+                bool found = false;
+                if (lo == hi) found = true;
+                else if (cT == 0 && base > lo) hi = base;
+                else if (cT == len && base + len < hi) lo = base + len;
+                else { found = true; lo = hi = base + cT; }
+                const float rho = (len == KL_BLK && fb > fa) ? 63.0f / (fb - fa) : 0.0f;
+                if (found) {
+                    const int ct = (int)(lo - base);
+                    if (ct < len) { // the block holds the rank: the prefix sum there = the block's fine prefix + the images in front of it
+                        rank = lo; pfr = pfx; rho_found = rho; st = 2;
 #pragma unroll
-                            for (int t = 0; t < 8; t++) {
-                                const int idx = (t < 4) ? 4 * gl + t : 32 + 4 * gl + (t - 4);
-                                if (idx < ca) pa_part += fix_f32(x[t] - mean, Sft);
-                            }
-                        } // else: a sits right behind this block; the next round reads that one (lo == hi)
-                    } else {
-                        misses++;
-                        const float rho = (len == KL_BLK && fb > fa) ? 63.0f / (fb - fa) : 0.0f;
-                        mode = 1;
-                        if (rho > 0.0f && misses <= 2) {
-                            const double pr = (cL == 0) ? (double)base + (Lt - (double)fa) * (double)rho
-                                                        : (double)(base + 63) + (Lt - (double)fb) * (double)rho;
-                            if (pr >= (double)lo && pr < (double)hi) { mode = 0; pred = (long long)pr; }
-                        }
-                        if (hi - lo <= KL_BLK) { mode = 0; pred = lo; }
-                    }
-                }
-                if (label) {
-                    const int ce = cE > ca ? cE : ca;
-#pragma unroll
-                    for (int t = 0; t < 8; t++) {
-                        const int idx = (t < 4) ? 4 * gl + t : 32 + 4 * gl + (t - 4);
-                        if (idx >= ca && idx < ce) {
-                            const float xc = x[t] - mean;
-                            const float d0 = q0 + (-2.0f * (xc * c0));
-                            const float d1 = q1 + (-2.0f * (xc * c1));
-                            const int q = fix_f32(xc, Sft);
-                            if (d1 < d0 || (d1 == d0 && tie1)) { s1 += q; n1++; } else { s0 += q; n0++; }
+                        for (int t = 0; t < 8; t++) { const int idx = (t < 4) ? 4 * gl + t : 32 + 4 * gl + (t - 4); if (idx < ct) part += fix_f32(x[t], Sft); }
+                    } // else: the rank sits right behind this block; the next round reads that one (lo == hi)
+                } else {
+                    misses++;
+                    mode = 1;
+                    if (rho > 0.0f && misses <= 2) {
+                        const float sh = (cT == 0) ? (T - fa) * rho : 63.0f + (T - fb) * rho;
+                        if (sh > -1.0e9f && sh < 1.0e9f) {
+                            const long long pr = (long long)base + (long long)sh;
+                            if (pr >= (long long)lo && pr < (long long)hi) { mode = 0; pred = (IDX)pr; }
                         }
                     }
-                    und += ce - ca;
-                    if (ce >= len && base + len < n) { st = 1; pred = base + len; if (und > KL_TAIL_MAX) st = 3; }
-                    else { b = base + ce; st = 2; }
+                    if (hi - lo <= KL_BLK) { mode = 0; pred = lo; }
                 }
             } else if (scanmode) {
-                if (cL > 0) lo = ra + 1;
-                if (cL < 8) hi = rb;
+                const IDX ra = lo + (IDX)(((long long)w * cT) / 9), rb = lo + (IDX)(((long long)w * (cT + 1)) / 9); // the last probe that passes, the first that does not
+                if (cT > 0) lo = ra + 1;
+                if (cT < 8) hi = rb;
                 misses = 0;
                 mode = 1;
                 if (hi - lo <= KL_BLK) { mode = 0; pred = lo; }
-                else if (cL > 0 && cL < 8 && fb > fa) {
-                    double pr = (double)ra + (Lt - (double)fa) * ((double)(rb - ra) / ((double)fb - (double)fa));
+                else if (cT > 0 && cT < 8 && fb > fa) {
+                    double pr = (double)ra + ((double)T - (double)fa) * ((double)(rb - ra) / ((double)fb - (double)fa));
                     if (!(pr >= (double)lo)) pr = (double)lo;
                     if (!(pr <= (double)(hi - 1))) pr = (double)(hi - 1);
-                    mode = 0; pred = (long long)pr;
+                    mode = 0; pred = (IDX)pr;
                 }
             }
-            if (!__any(st < 2)) break;
+#ifdef NNC_DIAG
+            if (threadIdx.x == 0) dg->ph[3] += 1; // rounds of the first wave
+#endif
+            if (!__any(st == 0)) break;
         }
-        if (st < 2) st = 3;
-        // ---- the group's totals; its first lane writes them down
-        const long long PAs = grp8_sum_ll(pa_part), S0 = grp8_sum_ll(s0), S1 = grp8_sum_ll(s1);
-        const int N01 = grp8_sum_i(n0 | (n1 << 16));
+        if (st == 0) st = 3;
+        KLSUB(3); // the general rounds
+        const long long PS = grp8_sum_ll(part);
         if (have && gl == 0) {
             if (st == 2) {
-                const long long pa = pfa + PAs;
-                L.A[j] = a; L.PA[j] = pa; L.B[j] = b; L.PB[j] = pa + S0 + S1;
-                const int N0 = N01 & 0xFFFF, N1 = N01 >> 16;
-                if (N0) { atomicAdd(reinterpret_cast<unsigned long long *>(&L.sum_s[j]), (unsigned long long)S0); atomicAdd(reinterpret_cast<unsigned long long *>(&L.cnt_s[j]), (unsigned long long)N0); }
-                if (N1) { atomicAdd(reinterpret_cast<unsigned long long *>(&L.sum_s[j + 1]), (unsigned long long)S1); atomicAdd(reinterpret_cast<unsigned long long *>(&L.cnt_s[j + 1]), (unsigned long long)N1); }
-                L.hint[j] = a; L.hL[j] = (float)Lt; L.hR[j] = rho_found;
-            } else hd->slow = 1;
+                if (si & 1) { L.B[jj] = (long long)rank; L.PB[jj] = pfr + PS; } else { L.A[jj] = (long long)rank; L.PA[jj] = pfr + PS; }
+                // the density for the next Newton step: over the move just made where that was long enough to measure one (the 64 or
+                // 128 samples of one probe give the local density to some ten per cent only), else the probe's
+                float rnew = rho_found;
+                {
+                    const float dT = T - L.hL[si];
+                    const long long dr = (long long)rank - L.hint[si];
+                    if (L.hint[si] >= 0 && (dr >= 256 || dr <= -256) && dT != 0.0f) {
+                        const float sec = (float)dr / dT;
+                        if (sec > 0.0f && sec < 3.0e38f) rnew = sec;
+                    }
+                }
+                L.hint[si] = (long long)rank; L.hL[si] = T; L.hR[si] = rnew;
+            } else {
+                hd->slow = 1;
+#ifdef NNC_DIAG
+                hd->pad0 = si; hd->pad1 = st; hd->pad2 = (int)(hi - lo);
+#endif
+            }
+        }
+        KLSUB(4); // results written
+    }
+}
+
+#define KL_CHUNK 256  // samples of one labelling chunk (two candidates per sample)
+#define KL_CHUNK_CROWD 32 // ... where three or more centres are candidates (each sample is a loop over them): spread over more groups
+#define KL_QMAX 4096  // chunks one iteration may label inside the loop (a million samples); beyond that the wide pass takes the iteration
+#define KL_QONE 512   // ... and so many of them from one boundary
+
+// between the passes: the chunk list (one thread per boundary)
+template <int NT>
+__device__ __forceinline__ void kl_chunks(const int ku, KlHead *hd, const KlArr &L)
+{
+    const int tid = threadIdx.x, nb = ku - 1;
+    int *qfirst = reinterpret_cast<int *>(L.call); // (free between two finish steps)
+    for (int j = tid; j < nb; j += NT) {
+        const long long bm = j > 0 ? L.B[j - 1] : 0, a = L.A[j], e = L.B[j];
+        const long long s = a > bm ? a : bm;
+        const long long len = e - s;
+        if (len > 0) {
+            const int cs_ = (int)L.phi[j] == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
+            const long long nc = (len + cs_ - 1) / cs_;
+            if (nc > KL_QONE) hd->slow = 1;
+            else {
+                const int first = atomicAdd(&hd->nch, (int)nc);
+                qfirst[j] = first;
+                for (int i = 0; i < (int)nc; i++) if (first + i < KL_QMAX) L.qj[first + i] = (uint16_t)j;
+            }
+        }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void kl_label(const float *__restrict__ xs, const float mean, const int Sft, KlHead *hd, const KlArr &L)
+{
+    const int tid = threadIdx.x, g = tid >> 3, gl = tid & 7;
+    const int nch = hd->nch;
+    const int *qfirst = reinterpret_cast<const int *>(L.call);
+    for (int c = g; c < nch; c += NT / 8) {
+        const int j = (int)L.qj[c];
+        const long long bm = j > 0 ? L.B[j - 1] : 0, a = L.A[j], e = L.B[j];
+        const long long s = a > bm ? a : bm;
+        const int phi = L.phi[j];
+        const bool two = phi == j + 1;
+        const int cs_ = two ? KL_CHUNK : KL_CHUNK_CROWD;
+        const long long start = s + (long long)cs_ * (c - qfirst[j]);
+        const long long end = start + cs_ < e ? start + cs_ : e;
+        const float c0 = L.cs[j], q0 = L.csq[j], c1 = L.cs[j + 1], q1 = L.csq[j + 1];
+        const bool tie1 = L.so[j + 1] < L.so[j];
+        long long s0 = 0, s1 = 0;
+        int n0 = 0, n1 = 0;
+        for (long long r0 = start + gl; r0 < end; r0 += 64) { // eight loads a lane in flight
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const long long r = r0 + 8 * u; v[u] = r < end ? xs[r] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (r0 + 8 * u < end) {
+                    const float xc = v[u] - mean;
+                    const int q = fix_f32(xc, Sft);
+                    if (two) {
+                        const float d0 = q0 + (-2.0f * (xc * c0));
+                        const float d1 = q1 + (-2.0f * (xc * c1));
+                        if (d1 < d0 || (d1 == d0 && tie1)) { s1 += q; n1++; } else { s0 += q; n0++; }
+                    } else {
+                        float bestd = q0 + (-2.0f * (xc * c0));
+                        int best = j, besto = (int)L.so[j];
+                        for (int cc = j + 1; cc <= phi; cc++) {
+                            const float d = L.csq[cc] + (-2.0f * (xc * L.cs[cc]));
+                            const int oc = (int)L.so[cc];
+                            if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = cc; besto = oc; }
+                        }
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&L.sum_s[best]), (unsigned long long)(long long)q);
+                        atomicAdd(reinterpret_cast<unsigned long long *>(&L.cnt_s[best]), 1ull);
+                    }
+                }
+            }
+        }
+        const long long S0 = grp8_sum_ll(s0), S1 = grp8_sum_ll(s1);
+        const int N01 = grp8_sum_i(n0 | (n1 << 16));
+        if (gl == 0) {
+            const int N0 = N01 & 0xFFFF, N1 = N01 >> 16;
+            if (N0) { atomicAdd(reinterpret_cast<unsigned long long *>(&L.sum_s[j]), (unsigned long long)S0); atomicAdd(reinterpret_cast<unsigned long long *>(&L.cnt_s[j]), (unsigned long long)N0); }
+            if (N1) { atomicAdd(reinterpret_cast<unsigned long long *>(&L.sum_s[j + 1]), (unsigned long long)S1); atomicAdd(reinterpret_cast<unsigned long long *>(&L.cnt_s[j + 1]), (unsigned long long)N1); }
         }
     }
 }
@@ -475,7 +655,7 @@ __device__ __forceinline__ void kl_boundaries(const float *__restrict__ xs, cons
 template <int NT>
 __device__ __forceinline__ int kl_finish(KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total, const int k,
                                          const int kc, int &cur, int &iter, const int Sft, const int max_iter, const float tol_v, const float p_lo,
-                                         const float p_hi)
+                                         const float p_hi, KlDiag *dg)
 {
     const int tid = threadIdx.x;
     const int ku = hd->ku;
@@ -504,23 +684,24 @@ __device__ __forceinline__ int kl_finish(KmWs *__restrict__ ws, KlHead *hd, cons
     // ---- could the labels equal the previous iteration's?  (only if every cluster kept its count)  Empty clusters?
     int diff = 0, my_empty = 0;
     for (int j = tid; j < k; j += NT) {
-        const long long c = cnto[j];
+        const long long c = cnto[j], sm = sumo[j];
         diff |= (L.prevc[j] != c);
         L.prevc[j] = c;
         my_empty += (c == 0);
+        // (what the relocation kernels edit, and what nnc_kmeans_partials shows: the sums / counts of the iteration, as k_finalize leaves them)
+        ws->partials[j] = sm; ws->partials[k + j] = c;
+        ws->partials_local[j] = sm; ws->partials_local[k + j] = c;
     }
+    KLSTAMP(5); // combine + scatter
     const int any_diff = __syncthreads_or(diff);
     const int any_empty = __syncthreads_or(my_empty);
+    KLSTAMP(6); // votes
     if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
     if (any_empty) {
         if (tid == 0) hd->n_empty = 0;
         __syncthreads();
         if (my_empty) atomicAdd(&hd->n_empty, my_empty);
         __syncthreads();
-        for (int j = tid; j < k; j += NT) {
-            ws->partials[j] = sumo[j]; ws->partials[k + j] = cnto[j];
-            ws->partials_local[j] = sumo[j]; ws->partials_local[k + j] = cnto[j];
-        }
         if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = hd->n_empty; ws->tab[cur].n_ovf = 0; }
         return 2;
     }
@@ -548,7 +729,185 @@ __device__ __forceinline__ int kl_finish(KmWs *__restrict__ ws, KlHead *hd, cons
     }
     for (int j = tid; j < k; j += NT) { const float c = L.cnew[j]; ws->c[cur][j] = c; L.cold[j] = c; }
     __syncthreads();
-    kl_tables<NT>(ws, hd, L, k, cur, false, p_lo, p_hi);
+    KLSTAMP(7); // shift, pairwise sum, state
+    kl_tables<NT>(ws, hd, L, k, cur, false, p_lo, p_hi, dg);
+    return done ? 1 : 0;
+}
+
+// ---- the same step when nothing unusual happens: every centre distinct (one thread per cluster, k <= NT), no empty cluster, the
+// order of the centres unchanged.  Then nothing has to change places: thread p owns the p-th centre in value order from the sums
+// to the zones, and the step needs six workgroup barriers instead of some forty.  Returns -1 (before it has changed anything
+// that the general step would not change in the same way) when that does not hold; else 0 = go on, 1 = stopped, 2 = paused.
+template <int NT>
+__device__ __forceinline__ int kl_finish_fast(KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total, const int k,
+                                              int &cur, int &iter, const int Sft, const int max_iter, const float tol_v, const float p_lo,
+                                              const float p_hi, KlDiag *dg)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int p = tid;
+    const bool mine = p < k;
+    // ---- this cluster's sum and count: the certain stretch [b_{p-1}, a_p) from the prefix sums + what the labelling added
+    long long sm = 0, c = 0;
+    int o = 0;
+    float cn = 0.0f;
+    int empty = 0, diff = 0;
+    if (mine) {
+        const long long lo_r = p > 0 ? L.B[p - 1] : 0, plo = p > 0 ? L.PB[p - 1] : 0;
+        const long long hi_r = p == k - 1 ? n : L.A[p], phi_ = p == k - 1 ? total : L.PA[p];
+        sm = L.sum_s[p]; c = L.cnt_s[p];
+        if (hi_r > lo_r) { sm += phi_ - plo; c += hi_r - lo_r; }
+        L.sum_s[p] = 0; L.cnt_s[p] = 0;
+        o = (int)L.so[p];
+        empty = c == 0;
+        diff = L.prevc[o] != c;
+        L.prevc[o] = c;
+        ws->partials[o] = sm; ws->partials[k + o] = c;
+        ws->partials_local[o] = sm; ws->partials_local[k + o] = c;
+        if (!empty) {
+            cn = (float)ldexp((double)sm / (double)c, -Sft);
+            const float d = cn - L.cold[o];
+            const float s2 = d * d;
+            const float sft = (float)sqrt((double)s2);
+            L.sq[o] = sft * sft;
+            L.cnew[o] = cn;
+        }
+    }
+    if (__any(empty) && lane == 0) hd->f_empty = 1;
+    if (__any(diff) && lane == 0) hd->f_diff = 1;
+    __syncthreads();                                                                                   // ---- 1
+    KLSTAMP(5);
+    const int any_empty = hd->f_empty, any_diff = hd->f_diff;
+    if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
+    if (any_empty) { // pause: the relocation chain (or the host) takes over; nothing else of the state has changed
+        if (tid == 0) hd->n_empty = 0;
+        __syncthreads();
+        if (empty) atomicAdd(&hd->n_empty, 1);
+        __syncthreads();
+        if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = hd->n_empty; ws->tab[cur].n_ovf = 0; hd->f_empty = 0; hd->f_diff = 0; }
+        return 2;
+    }
+    // ---- NumPy's pairwise sum of the squared shifts (leaves now, eight lanes each; the first wave folds them behind the barrier),
+    // and: is the order of the centres still the same, all of them distinct?
+    KlHeap *hp = &hd->heap;
+    if (k <= LEAF) {
+        if (tid < 8) { const float r = kl_leaf_sum(L.sq, 0, k, tid & 7); if (tid == 0) hd->tot = r; }
+    } else {
+        const int depth = hd->depth;
+        for (int node = 1 + (tid >> 3); node < (2 << depth) && node < 64; node += NT / 8) {
+            const int l = hp->len[node];
+            if (l > 0 && l <= LEAF) { const float r = kl_leaf_sum(L.sq, hp->start[node], l, tid & 7); if ((tid & 7) == 0) hp->val[node] = r; }
+        }
+    }
+    int ok = 1;
+    if (mine && p + 1 < k) ok = cn < L.cnew[L.so[p + 1]]; // strictly: equal centres would have to be merged
+    if (!__all(ok) && lane == 0) hd->f_reorder = 1;
+
+    __syncthreads();                                                                                   // ---- 2
+    KLSTAMP(6);
+    if (tid < 64 && k > LEAF) {
+        for (int lev = hd->depth - 1; lev >= 0; lev--) {
+            const int i = (1 << lev) + lane;
+            if (lane < (1 << lev) && hp->len[i] > LEAF) hp->val[i] = hp->val[2 * i] + hp->val[2 * i + 1];
+            wave_lds_fence();
+        }
+        if (lane == 0) hd->tot = hp->val[1];
+    }
+    const int reorder = hd->f_reorder;
+    cur ^= 1;
+    iter += 1;
+    if (mine) { ws->c[cur][o] = cn; L.cold[o] = cn; }
+    if (reorder && tid == 0) ws->kl_stats[2] += 1; // (iterations in which centres changed places)
+    if (reorder) { // the general way for the tables (and only for them: the sums, the shift and the new centres are settled)
+        __syncthreads();
+        const float tot = hd->tot;
+        int done = 0;
+        if (tot <= tol_v) done = 1;
+        else if (iter >= max_iter) done = 2;
+        if (tid == 0) {
+            ws->st.iter = iter; ws->st.shift_tot = tot; ws->st.done = done; ws->st.paused = 0; ws->st.n_empty = 0; ws->cur = cur;
+            hd->f_reorder = 0; hd->f_diff = 0;
+        }
+        __syncthreads();
+        kl_tables<NT>(ws, hd, L, k, cur, false, p_lo, p_hi, dg);
+        return done ? 1 : 0;
+    }
+    // ---- the tables of the new centres: same order, same indices
+    KmTab *tab = &ws->tab[cur];
+    if (mine) {
+        const float v2 = cn * cn;
+        L.cs[p] = cn; L.csq[p] = v2;
+        tab->perm[p] = (uint16_t)o; tab->cand[p] = make_float2(cn, v2); tab->orig[p] = (uint16_t)o;
+        ws->bnd.cand[p] = make_float2(cn, v2); ws->bnd.orig[p] = (uint16_t)o;
+    }
+    if (tid == 0) { tab->ku = k; ws->ku_cur = k; ws->bnd.ku = k; tab->n_ovf = 0; ws->cells_pending = 0; hd->f_diff = 0; }
+    __syncthreads();                                                                                   // ---- 3
+    KLSTAMP(7);
+    const float tot = hd->tot;
+    int done = 0;
+    if (tot <= tol_v) done = 1;
+    else if (iter >= max_iter) done = 2;
+    if (tid == 0) { ws->st.iter = iter; ws->st.shift_tot = tot; ws->st.done = done; ws->st.paused = 0; ws->st.n_empty = 0; ws->cur = cur; }
+    // ---- zones (km_pair_zone), then U_p = the largest zone end of the centres up to p, S_p = the smallest one from p on: scans inside
+    // the wave by shuffles, across the waves through sixteen LDS words
+    const double xb = fmax(fabs((double)p_lo), fabs((double)p_hi));
+    double left = -INFINITY, right = INFINITY;
+    if (mine) {
+        const double cp = (double)cn;
+        for (int q = p + 1; q < k; q++) {
+            const double cq = (double)L.cs[q];
+            const double mid = 0.5 * (cp + cq);
+            const double delta = cq - cp;
+            if (mid - km_pair_slack(delta, xb) >= right) break;
+            if (delta > 0.0) right = fmin(right, km_pair_zone(cp, cq, xb).hi);
+        }
+        for (int q = p - 1; q >= 0; q--) {
+            const double cq = (double)L.cs[q];
+            const double mid = 0.5 * (cp + cq);
+            const double delta = cp - cq;
+            if (mid + km_pair_slack(delta, xb) <= left) break;
+            if (delta > 0.0) left = fmax(left, km_pair_zone(cq, cp, xb).lo);
+        }
+        tab->zl[p] = left; tab->zr[p] = right;
+        ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
+    }
+    double um = mine ? right : -INFINITY, sn = mine ? left : INFINITY; // (neutral where there is no centre)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double a = __shfl_up(um, off), b = __shfl_down(sn, off);
+        if (lane >= off) um = fmax(um, a);
+        if (lane + off < 64) sn = fmin(sn, b);
+    }
+    if (lane == 63) hd->wmax[wv] = um;
+    if (lane == 0) hd->wmin[wv] = sn;
+    __syncthreads();                                                                                   // ---- 4
+    KLSTAMP(10);
+    for (int w = 0; w < NT / 64; w++) {
+        if (w < wv) um = fmax(um, hd->wmax[w]);
+        if (w > wv) sn = fmin(sn, hd->wmin[w]);
+    }
+    if (mine) {
+        // thresholds of the boundaries either side of this centre: U_p (boundary p, above it) and L_{p-1} = S_p (boundary p - 1, below it)
+        L.Ub[p] = um;
+        float uf = (float)um;
+        if ((double)uf > um) uf = nextafterf(uf, -INFINITY);
+        L.Uf[p] = uf;
+        if (p > 0) {
+            L.Lb[p - 1] = sn;
+            float lf = (float)sn;
+            if ((double)lf < sn) lf = nextafterf(lf, INFINITY);
+            L.Lf[p - 1] = lf;
+        }
+        if (p == k - 1) { L.Lb[p] = INFINITY; L.Lf[p] = INFINITY; }
+    }
+    if (tid == 0) hd->ku = k;
+    __syncthreads();                                                                                   // ---- 5
+    if (mine && p + 1 < k) { // phi_p: the highest centre that can still win below U_p
+        int q = p + 1;
+        while (q + 1 < k && L.Lb[q] <= um) q++;
+        L.phi[p] = (uint16_t)q;
+    }
+    __syncthreads();                                                                                   // ---- 6
+    KLSTAMP(11);
     return done ? 1 : 0;
 }
 
@@ -559,6 +918,16 @@ __global__ __launch_bounds__(NT) void k_lloyd(const float *__restrict__ xs, long
                                               unsigned long long ticket)
 {
     extern __shared__ __align__(16) unsigned char kl_smem[];
+#ifdef NNC_DIAG
+    KlDiag dgs, *dg = &dgs;
+    for (int q = 0; q < 16; q++) dgs.ph[q] = 0;
+    for (int q = 0; q < 8; q++) dgs.sp[q] = 0;
+    dgs.slast = 0;
+    dgs.last = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = dgs.last;
+#else
+    KlDiag *dg = nullptr;
+#endif
     KlHead *hd;
     KlArr L;
     kl_carve(kl_smem, kc, &hd, &L);
@@ -581,37 +950,70 @@ __global__ __launch_bounds__(NT) void k_lloyd(const float *__restrict__ xs, long
             L.cold[j] = ws->c[cur][j];
             L.perm[j] = tab->perm[j];
             L.prevc[j] = ws->prev_counts[j];
-            L.hint[j] = ws->hint_a[j]; L.hL[j] = ws->kl_hL[j]; L.hR[j] = ws->kl_hR[j];
+            L.hint[2 * j] = ws->hint_a[j]; L.hint[2 * j + 1] = ws->hint_b[j];
+            L.hL[2 * j] = ws->kl_hL[2 * j]; L.hL[2 * j + 1] = ws->kl_hL[2 * j + 1];
+            L.hR[2 * j] = ws->kl_hR[2 * j]; L.hR[2 * j + 1] = ws->kl_hR[2 * j + 1];
         }
         for (int p = tid; p < ku0; p += NT) {
             const float2 c = ws->bnd.cand[p];
             L.cs[p] = c.x; L.csq[p] = c.y; L.so[p] = ws->bnd.orig[p];
             L.Lb[p] = ws->bnd.zl[p]; L.Ub[p] = ws->bnd.zr[p];
         }
-        if (tid == 0) { hd->ku = ku0; hd->slow = 0; hd->crowd = 0; hd->depth = 0; }
+        if (tid == 0) { hd->ku = ku0; hd->slow = 0; hd->nch = 0; hd->depth = 0; hd->f_empty = 0; hd->f_diff = 0; hd->f_reorder = 0; }
         if (tid < 64 && k > LEAF) kl_heap_build(hd, k);
         __syncthreads();
         kl_derive<NT>(hd, L, ku0);
         int ran = 0;
+        KLSTAMP(0); // prologue
         for (;;) {
             if (budget <= 0) break;
-            if (hd->crowd) { if (tid == 0) ws->wide = 1; break; }
-            kl_boundaries<NT>(xs, n, pf, total, mean, Sft, hd->ku, hd, L);
+#ifdef NNC_DIAG
+            if (tid == 0) dg->slast = __builtin_amdgcn_s_memrealtime();
+#endif
+            if (n < (1ll << 31) - 256) kl_search<NT, int>(xs, n, pf, total, mean, Sft, hd->ku, hd, L, dg);
+            else kl_search<NT, long long>(xs, n, pf, total, mean, Sft, hd->ku, hd, L, dg);
+            KLSTAMP(1); // this wave's searches
             __syncthreads();
-            if (hd->slow) { if (tid == 0) ws->wide = 1; break; }
-            const int r = kl_finish<NT>(ws, hd, L, n, total, k, kc, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi);
+            KLSTAMP(2); // ... until the last group is through
+            if (!hd->slow) kl_chunks<NT>(hd->ku, hd, L);
+            __syncthreads();
+            if (hd->slow || hd->nch > KL_QMAX) { if (tid == 0) { ws->wide = 1; ws->help_hint = 1; hd->slow = 1; } break; } // (a long stretch: every wave of the wide pass had better look at the tile queue)
+            kl_label<NT>(xs, mean, Sft, hd, L);
+            KLSTAMP(14); // this wave's labelling
+            __syncthreads();
+            if (tid == 0) hd->nch = 0;
+            KLSTAMP(15); // ... until the last group is through
+            int r = -1;
+            if (hd->ku == k && k <= NT) r = kl_finish_fast<NT>(ws, hd, L, n, total, k, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi, dg);
+            else r = kl_finish<NT>(ws, hd, L, n, total, k, kc, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi, dg);
             budget--; ran++;
             if (r) break;
         }
         // ---- what the other kernels (and the next launch of this one) pick up from the workspace
         __syncthreads();
+        if (tid == 0) { // where the iterations of this fit ran (nnc_kmeans_loop_stats)
+            ws->kl_stats[0] += ran;                                     // iterations (or attempts that paused) run by the loop
+            ws->kl_stats[1] += 1;                                       // launches that had something to do
+            if (ran == 0 || !(ws->st.done | ws->st.paused)) {
+                if (hd->slow) ws->kl_stats[3] += 1;                     // handed over: a long undecided stretch / a search that did not settle
+#ifdef NNC_DIAG
+                if (hd->slow) { ws->kl_stats[5] = hd->pad0; ws->kl_stats[6] = hd->pad1; ws->kl_stats[7] = hd->pad2; }
+#endif
+            }
+        }
         for (int j = tid; j < k; j += NT) {
-            const long long h = L.hint[j];
-            ws->hint_a[j] = h; ws->hint_b[j] = h; ws->kl_hL[j] = L.hL[j]; ws->kl_hR[j] = L.hR[j];
+            ws->hint_a[j] = L.hint[2 * j]; ws->hint_b[j] = L.hint[2 * j + 1];
+            ws->kl_hL[2 * j] = L.hL[2 * j]; ws->kl_hL[2 * j + 1] = L.hL[2 * j + 1];
+            ws->kl_hR[2 * j] = L.hR[2 * j]; ws->kl_hR[2 * j + 1] = L.hR[2 * j + 1];
             if (ran) ws->prev_counts[j] = L.prevc[j];
         }
     }
     if (tid == 0) ws->kl_budget = budget;
+#ifdef NNC_DIAG
+    KLSTAMP(4); // epilogue
+    dg->ph[12] = __builtin_amdgcn_s_memtime() - clk0; dg->ph[13] = __builtin_amdgcn_s_memrealtime() - rt0; // shader cycles, 10 ns ticks
+    if (tid == 0) { for (int q = 0; q < 16; q++) ws->kl_trace[q] += dg->ph[q]; for (int q = 0; q < 8; q++) ws->kl_trace[16 + q] += dg->sp[q]; }
+#endif
     if (host_st) {
         __syncthreads();
         if (tid == 0) {

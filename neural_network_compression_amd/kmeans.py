@@ -243,7 +243,7 @@ class DeviceKMeans:
                  batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
                  reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
                  n_total: int | None = None, n_min: int | None = None, comm=None, rank_boundaries: bool = True,
-                 two_launch: bool = False):
+                 two_launch: bool = False, loop: bool = False):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -292,7 +292,7 @@ class DeviceKMeans:
         self.fix_shift = ops.fix_shift(absmax, n_total)
 
         self.p = nat.KMeansParams(n=n, n_total=n_total, k=self.k, max_iter=int(max_iter), fix_shift=self.fix_shift,
-                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=nat.NNC_KM_TWO_LAUNCH if two_launch else 0,
+                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=nat.NNC_KM_TWO_LAUNCH if two_launch else (nat.NNC_KM_LOOP if loop else 0),
                                   x_mean=float(mean), tol=float(self.tol_), lo=float(lo), hi=float(hi))
         self.ws_bytes = self.L.nnc_kmeans_workspace_bytes(self.k)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)
@@ -344,9 +344,10 @@ class DeviceKMeans:
             self.p.prefix_dev = self.prefix.data_ptr()
         # few centres on one GPU: the library runs a whole batch of iterations as ONE launch that stops by itself at
         # convergence or at an empty cluster (include/nnc.h, nnc_kmeans_iterate_publish), so there is nothing to size
-        # the whole vector on one GPU, sorted, with prefix sums: the iterations run inside ONE resident workgroup (include/nnc.h,
-        # "The Lloyd loop in one workgroup"); two_launch=True keeps the launch-per-iteration forms (same results)
-        self.lloyd = self.prefix is not None and group is None and not two_launch
+        # the whole vector on one GPU, sorted, with prefix sums, up to NNC_KM_LOOP_KMAX centres: the iterations run inside ONE resident
+        # workgroup (include/nnc.h, "The Lloyd loop in one workgroup"); two_launch=True keeps the launch-per-iteration forms,
+        # loop=True takes the loop whatever K (same results either way)
+        self.lloyd = self.prefix is not None and group is None and not two_launch and (loop or self.k <= nat.NNC_KM_LOOP_KMAX)
         self.one_launch = self.prefix is not None and group is None and self.k <= 64 and int(grid_log2) <= 11 and not self.lloyd
 
     # -------------------------------------------------------------- low-level steps
@@ -384,6 +385,13 @@ class DeviceKMeans:
     def status(self) -> nat.KMeansStatus:
         """The device state after everything enqueued so far."""
         return self.wait(self.publish())
+
+    def loop_stats(self) -> dict:
+        """Where the iterations ran so far (include/nnc.h, nnc_kmeans_loop_stats): inside the one-workgroup loop, or handed to the
+        multi-workgroup pass.  Synchronises."""
+        out = (ctypes.c_int32 * 8)()
+        nat.check(self.L.nnc_kmeans_loop_stats(self.ws.data_ptr(), out, self.stream))
+        return {"loop_iterations": out[0], "loop_launches": out[1], "reordered": out[2], "handed_over": out[3], "wide_iterations": out[4]}
 
     def iterate_and_look(self, iters: int) -> nat.KMeansStatus:
         """`iters` iterations and the state behind them.  On one GPU the look-in rides on the batch's last launch."""

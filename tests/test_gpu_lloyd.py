@@ -46,7 +46,7 @@ def _init(x, k, mode, seed=0):
 
 def _both(km, x, init, oracle=True):
     t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
-    a_km = km.DeviceKMeans(t, init)
+    a_km = km.DeviceKMeans(t, init, loop=True)
     assert a_km.lloyd, "the one-workgroup loop must be the path taken"
     a, av = a_km.fit()
     b, bv = km.DeviceKMeans(t, init, two_launch=True).fit()
@@ -124,7 +124,7 @@ def test_iteration_by_iteration(km, n, k):
     x = _pruned(n, 77 + k)
     init = _init(x, k, "quantile" if k > 64 else "linear")
     t = torch.from_numpy(x).cuda()
-    a, b = km.DeviceKMeans(t, init), km.DeviceKMeans(t, init, two_launch=True)
+    a, b = km.DeviceKMeans(t, init, loop=True), km.DeviceKMeans(t, init, two_launch=True)
     for it in range(12):
         sa, sb = a.iterate_and_look(1), b.iterate_and_look(1)
         assert (sa.iter, sa.done, sa.paused, sa.n_empty) == (sb.iter, sb.done, sb.paused, sb.n_empty), it
@@ -140,10 +140,27 @@ def test_iterate_runs_exactly_the_iterations_asked_for(km):
     x = synth.weights((300_000,), 5151)
     init = _init(x, 64, "linear")
     t = torch.from_numpy(x).cuda()
-    a = km.DeviceKMeans(t, init)
+    a = km.DeviceKMeans(t, init, loop=True)
     for want in (1, 3, 8):
         before = a.status().iter
         st = a.iterate_and_look(want)
         assert st.paused or st.done or st.iter == before + want, (before, want, st.iter)
         if st.paused or st.done:
             break
+
+
+def test_the_iterations_really_run_inside_the_loop(km):
+    """The device's own counters: a plain fit runs (nearly) all of its iterations in the one-workgroup loop, none by the wide pair --
+    by default up to NNC_KM_LOOP_KMAX centres, with loop=True beyond."""
+    x = _pruned(400_000, 4711)
+    t = torch.from_numpy(x).cuda()
+    for k, kw in ((16, {}), (64, {}), (257, {"loop": True})):
+        d = km.DeviceKMeans(t, _init(x, k, "quantile" if k > 64 else "linear"), **kw)
+        assert d.lloyd
+        m, _ = d.fit()
+        st = d.loop_stats()
+        assert st["loop_iterations"] >= m.n_iter_ and st["wide_iterations"] <= 1, (k, m.n_iter_, st)
+    d = km.DeviceKMeans(t, _init(x, 257, "quantile"))
+    assert not d.lloyd   # one compute unit's instruction rate is the bound there: launch per iteration
+    d.fit()
+    assert d.loop_stats()["loop_iterations"] == 0

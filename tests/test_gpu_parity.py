@@ -183,6 +183,26 @@ def test_estep_midpoint_stress(nnc):
     assert np.array_equal(labels, want), int((labels != want).sum())
 
 
+def test_estep_around_the_decision_intervals(nnc):
+    """Every float32 value for hundreds of ulps either side of every neighbour midpoint (the decision interval of a pair is some
+    tens to a few hundred ulps wide: csrc/nnc_hip.hip, km_pair_zone), K = 64 and K = 257, dense middle and sparse tails: the
+    labels are the brute-force float32 arg-min's."""
+    for k, span, seed in ((64, 700, 5151), (257, 260, 5152)):
+        cs = np.sort(synth.weights((k,), seed, scale=0.05))
+        mids = ((cs[:-1].astype(np.float64) + cs[1:].astype(np.float64)) / 2).astype(np.float32)
+        ints = mids.view(np.int32).astype(np.int64)
+        offs = np.arange(-span, span + 1, dtype=np.int64)
+        grid = ints[:, None] + np.where(mids[:, None] >= 0, offs[None, :], -offs[None, :])   # the next float32 up is the next integer up for x > 0
+        x = np.concatenate([grid.astype(np.int32).view(np.float32).ravel(), synth.weights((30_000,), seed + 1, scale=0.05),
+                            np.array([0.27, -0.27], dtype=np.float32)])   # (the largest |x| sets the global bound)
+        c = cs.copy()
+        np.random.RandomState(seed).shuffle(c)
+        km, labels, _, _ = _estep_gpu(nnc, x, c)
+        mean = orc.np_mean(x)
+        want = orc.estep((x - mean).astype(np.float32), (c - mean).astype(np.float32))
+        assert np.array_equal(labels, want), (k, int((labels != want).sum()))
+
+
 # ------------------------------------------------------------------ full fits
 def _input_for_quant(key):
     from tests.golden.make_goldens import lenet300_tensors, lenet5_tensors, q_for

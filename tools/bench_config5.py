@@ -10,11 +10,12 @@ shapes = synth.gpt2_small_layers()
 dev = torch.device("cuda:0")
 tensors = [(n, torch.from_numpy(synth.weights(s, 5000 + i)).to(dev)) for i, (n, s) in enumerate(shapes)]
 total = sum(t.numel() for _, t in tensors)
+TWO = os.environ.get("NNC_TWO_LAUNCH", "0") not in ("", "0")   # compare: Lloyd iterations launch by launch
 def run(workers):
     bits = iters = reloc = 0
     clones = [t.clone() for _, t in tensors]
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    res = pipeline.compress_layers(clones, workers=workers, q=1.0, bits=4, mode="linear", huffman=True, want_values=True)
+    res = pipeline.compress_layers(clones, workers=workers, q=1.0, bits=4, mode="linear", huffman=True, want_values=True, two_launch=TWO)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     for r in res:
         bits += int(r.total_bits or 0); iters += r.model.n_iter_ if r.model else 0; reloc += r.model.n_relocations_ if r.model else 0
@@ -28,7 +29,7 @@ for workers in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
 by = {}
 for _, t in tensors:
     c = t.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
-    r = pipeline.compress_layer(c, q=1.0, bits=4, mode="linear", huffman=True, want_values=True)
+    r = pipeline.compress_layer(c, q=1.0, bits=4, mode="linear", huffman=True, want_values=True, two_launch=TWO)
     torch.cuda.synchronize(); d = time.perf_counter() - t0
     e = by.setdefault(t.numel(), [0, 0.0, 0]); e[0] += 1; e[1] += d; e[2] += r.model.n_iter_
 for n in sorted(by):
