@@ -202,8 +202,8 @@ def main():
     # kernels of the Lloyd loop (some 110 launches a step) are timed in one more step afterwards, outside the timed region.
     STREAM_TAGS = (1 << 0) | (1 << 2) | (1 << 3) | (1 << 4) | (1 << 6) | (1 << 7)
     dt, all_ms, all_tags, res = profiled(args.steps, STREAM_TAGS)
-    _, ms_k, tags_k, _ = profiled(1, (1 << 1) | (1 << 5))
-    per_step_scale = {1: 1.0, 5: 1.0}
+    _, ms_k, tags_k, _ = profiled(1, (1 << 1) | (1 << 5) | (1 << 8) | (1 << 9))
+    per_step_scale = {1: 1.0, 5: 1.0, 8: 1.0, 9: 1.0}
 
     # The streaming form of the Lloyd pass (k_assign<accumulate>: what an iteration costs on a vector that is NOT sorted, and
     # the fallback of the rank-boundary form) timed on its own, outside the timed region: 30 launches on the same sorted
@@ -244,9 +244,9 @@ def main():
         label_bytes = 1 if k_fit <= 256 else 2
         # per-kernel durations over the timed region (HIP events on the launching stream, in-library)
         names = {0: "k_assign<accumulate>", 1: "k_bounds", 2: "k_assign<labels>", 3: "k_threshold", 4: "k_chunk_sums", 5: "k_finalize",
-                 6: "k_prefix_blocks", 7: "k_minmax"}
+                 6: "k_prefix_blocks", 7: "k_minmax", 8: "k_lloyd", 9: "k_reloc_*"}
         # algorithmic bytes per weight and launch; None: not a pass over the vector
-        bpw = {0: 4, 1: None, 2: 4 + label_bytes + 4, 3: 9, 4: 4, 5: None, 6: 4, 7: 4}
+        bpw = {0: 4, 1: None, 2: 4 + label_bytes + 4, 3: 9, 4: 4, 5: None, 6: 4, 7: 4, 8: None, 9: None}
         kernels = {}
         for tag, name in names.items():
             d = all_ms[all_tags == tag]
@@ -256,7 +256,7 @@ def main():
                 nst = 1
             if d.size == 0:
                 continue
-            live = d[d > 0.5 * np.median(d)] if tag in (0, 1, 5) else d   # launches enqueued behind a stop / pause return at once
+            live = d[d > 0.5 * np.median(d)] if tag in (0, 1, 5, 8, 9) else d   # launches enqueued behind a stop / pause return at once
             ent = {"launches_per_step": d.size / nst, "avg_ms": float(live.mean()), "median_ms": float(np.median(live)),
                    "ms_per_step": float(d.sum() / nst), "timed": "timed region" if nst == args.steps and tag not in per_step_scale else "one extra step"}
             if bpw[tag] is not None:
@@ -264,13 +264,18 @@ def main():
                 ent["achieved_GBps"] = bpw[tag] * n_loc / (ent["avg_ms"] * 1e-3) / 1e9
                 ent["frac_of_hbm_peak"] = ent["achieved_GBps"] / HBM_PEAK_GBS
             kernels[name] = ent
-        traffic = None
-        tr_path = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tr_path):
-            try:
-                traffic = json.load(open(tr_path)).get("k_assign_labels_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        # HBM bytes per launch of the roofline kernel from the PMC passes of tools/make_profiles.sh (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), if this round's summary is in the tree: a number measured in
+        # another run of the same command, labelled as such -- bench.py itself cannot read the counters
+        traffic, traffic_source = None, None
+        for cand in ("r03_pmc_hbm_summary.json",):
+            tr_path = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(tr_path):
+                try:
+                    traffic = json.load(open(tr_path)).get("k_assign_labels_hbm_bytes_per_launch")
+                    traffic_source = f"profiles/{cand}: separate rocprofv3 --pmc passes over `python bench.py --steps 3 --warmup 1`, not this run"
+                except Exception:
+                    traffic = None
         lab = kernels.get("k_assign<labels>", {})
         out = {
             "metric": "weights/sec through prune+k-means (K=256)",
@@ -299,12 +304,28 @@ def main():
                 "bound": "hbm", "kernel": "k_assign<labels> (final E-step: 4 B read + centroid index + 4 B decoded value written per weight)",
                 "achieved": lab.get("achieved_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": lab.get("frac_of_hbm_peak"),
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "avg_kernel_ms": lab.get("avg_ms"), "launches_timed": int((all_tags == 2).sum()),
+                "timing": "HIP events around the launch, inside the timed region (rocprofv3 --kernel-trace of the same command: profiles/r03_bench_kernel_stats.csv)",
                 "algorithmic_bytes_per_launch": lab.get("algorithmic_bytes_per_launch"),
             },
             "kernels": kernels,
         }
+        # The step as a whole against the same peak: the bytes no implementation of this pipeline could avoid moving, over the step
+        # time -- and how much of the step sits in K-sized kernels (the Lloyd iterations and the relocation events read a few MB
+        # each: latency, not bandwidth, is what they cost).  Per weight: the in-place pass needs its own copy of the input (4 r + 4 w),
+        # sigma = two passes (8 r), threshold (4 r + 4 w + 1 w mask), mean / variance of the pruned tensor (8 r), labels + values
+        # (4 r + index + 4 w); per surviving weight: the value sort (one read, one write of the sorted copy: 8) and the prefix pass (4 r).
+        if res.model is not None and res.nzeroed is not None:
+            nnz = n_loc - int(res.nzeroed)
+            step_bytes = n_loc * (8 + 8 + 9 + 8 + 4 + label_bytes + 4) + nnz * (8 + 4)
+            ksz = sum(kernels[nm]["ms_per_step"] for nm in ("k_bounds", "k_finalize", "k_lloyd", "k_reloc_*") if nm in kernels)
+            out["roofline_step"] = {
+                "bound": "hbm", "unavoidable_bytes_per_step": int(step_bytes), "achieved": step_bytes / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                "k_sized_kernel_ms_per_step": ksz, "k_sized_share_of_step": ksz / (dt / args.steps * 1e3),
+                "note": "roofline.frac describes one kernel (the assignment pass over the vector); this is the whole step",
+            }
         if stream_ms.size:
             a = 4.0 * n_loc / (stream_ms.mean() * 1e-3) / 1e9
             out["roofline_streaming_accumulate"] = {

@@ -128,9 +128,14 @@ int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *sig
  * x, as after nnc_prune_f32 with threshold thr; vmin / vmax from nnc_minmax_signs_f32): their order-preserving integer images
  * relative to the two ends fit in nnc_sort_pruned_bounded_bits(...) bits (0: the form does not apply -- no threshold, or more
  * than 27 bits), and a hand-written radix sort of those compact keys takes three passes of at most 9 bits instead of the four
- * 8-bit passes of the general 32-bit sort.  Same result as nnc_sort_pruned_f32. */
+ * 8-bit passes of the general 32-bit sort.  Same result as nnc_sort_pruned_f32.  Every non-zero weight must lie in [vmin, -thr] or
+ * [thr, vmax]: a weight outside (or a NaN) is clamped to the nearest end -- nothing is written out of range, but the sorted
+ * vector then holds a value the input does not -- and the int32 at nnc_sort_pruned_bounded_flag(ws, n_nonzero) (device memory inside
+ * the workspace) is non-zero once the sort has run; nnc_compress_layer_f32 checks it and hands such a tensor to its caller's own
+ * path (status NNC_LAYER_HOST). */
 int32_t nnc_sort_pruned_bounded_bits(float vmin, float vmax, float thr, int64_t n_neg, int64_t n_pos);
 size_t nnc_sort_pruned_bounded_workspace_bytes(int64_t n_nonzero);
+const int32_t *nnc_sort_pruned_bounded_flag(void *ws, int64_t n_nonzero);
 int nnc_sort_pruned_bounded_f32(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float vmin, float vmax, float thr,
                                 float *sorted_out, void *ws, size_t ws_bytes, void *stream);
 
@@ -525,6 +530,9 @@ int nnc_gather_f32(const float *centers_dev, int32_t k, const void *labels, int 
 #define NNC_MIN 2
 /* Rank 0 makes the id, the caller carries the NNC_COMM_ID_BYTES bytes to the other ranks (any channel), every rank calls
  * nnc_comm_init on the thread whose current device is its GPU (blocking rendezvous). */
+/* NNC_OK if librccl can be bound in this process (creates nothing).  nnc_comm_init blocks until every rank has entered it, so the
+ * ranks should agree (over the caller's own group) that all of them can, before any of them does. */
+int nnc_comm_available(void);
 int nnc_comm_unique_id(void *id_out, size_t len);
 int nnc_comm_init(void **comm_out, const void *id, size_t len, int32_t rank, int32_t world);
 int nnc_comm_destroy(void *comm);
@@ -562,6 +570,7 @@ int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void
 #define NNC_PROF_PREFIX 6            /* k_prefix_blocks */
 #define NNC_PROF_MINMAX 7            /* k_minmax */
 #define NNC_PROF_LLOYD 8             /* k_lloyd: the one-workgroup Lloyd loop (any number of iterations per launch) */
+#define NNC_PROF_RELOC 9             /* the windowed empty-cluster relocation: k_reloc_head / windows / dist / select (K-sized) */
 /* Which tags get events from now on (bit t = NNC_PROF_* tag t; default all): an event pair costs its launch a little, so a
  * timed run may want the passes over the vector only. */
 int nnc_profile_tags(uint32_t mask);

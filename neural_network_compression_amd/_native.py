@@ -79,6 +79,7 @@ SIGNATURES = {
     "nnc_prune_f32": (c_int, [c_void_p, c_i64, c_f32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_sort_pruned_bounded_bits": (c_i32, [c_f32, c_f32, c_f32, c_i64, c_i64]),
     "nnc_sort_pruned_bounded_workspace_bytes": (c_size, [c_i64]),
+    "nnc_sort_pruned_bounded_flag": (c_void_p, [c_void_p, c_i64]),
     "nnc_sort_pruned_bounded_f32": (c_int, [c_void_p, c_i64, c_i64, c_i64, c_f32, c_f32, c_f32, c_void_p, c_void_p, c_size, c_void_p]),
     "nnc_prune_stats_workspace_bytes": (c_size, [c_i64]),
     "nnc_prune_stats_f32": (c_int, [c_void_p, c_i64, c_f32, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size, c_void_p]),
@@ -160,6 +161,7 @@ SIGNATURES = {
     "nnc_merge_keys": (c_int, [c_void_p, c_i32, c_i32, c_void_p, c_i32, c_void_p]),
     "nnc_kmeans_reloc_scratch_bytes_sharded": (c_size, [c_i32, c_i32, c_i32]),
     "nnc_kmeans_relocate_windowed_sharded": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, c_size, c_void_p]),
+    "nnc_comm_available": (c_int, []),
     "nnc_profile_tags": (c_int, [ctypes.c_uint32]),
     "nnc_profile_begin": (c_int, [c_i32]),
     "nnc_profile_end": (c_int, [ctypes.POINTER(c_f32), ctypes.POINTER(c_i32), c_i64, ctypes.POINTER(c_i64)]),

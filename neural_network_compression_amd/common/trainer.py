@@ -76,17 +76,40 @@ class Trainer(ABC):
     def quantize(self, test_dataset: LeNetDataset, with_cumulative_weight_distribution: bool,
                  maximum_centroid_bits: int, k_means_initialization_mode: str) -> float:
         self.quantized_models_by_layer = {}   # layer -> [fitted model or None per tensor]: what fine_tune_centroids needs
-        for _layer_name, layer in self.neural_network.get_config().items():
+        layers = [layer for _layer_name, layer in self.neural_network.get_config().items()]
+        # The tensors of the network are independent: where the init draws nothing from NumPy's global generator (linear,
+        # density) they go through the library's one-call layer, several side by side on streams of their own
+        # (pipeline.compress_layers) -- the same results as the calls below one after the other
+        # (tests/test_gpu_config5.py::test_layer_as_one_library_call_equals_the_step_by_step_path, test_layers_side_by_side_...).
+        # Everything else -- forgy / kmeans++ (global generator, in layer order), tensors too short for the number of centroids
+        # (the reference's "not enough bits" pass-through), the error cases -- takes the reference's own sequence of calls.
+        mode, bits = k_means_initialization_mode, maximum_centroid_bits
+        batched = {}
+        if mode in ("linear", "density") and (mode != "density" or with_cumulative_weight_distribution) and isinstance(bits, int) and 1 <= bits <= 10:
+            from .. import pipeline
+
+            todo = [(li, ti, params) for li, layer in enumerate(layers) for ti, params in enumerate(layer.get_weights())
+                    if isinstance(params, torch.Tensor) and params.is_cuda and params.dtype == torch.float32 and params.is_contiguous()
+                    and params.numel() >= 2 ** bits + 1]
+            if todo:
+                res = pipeline.compress_layers([p.reshape(-1) for _, _, p in todo], workers=8, q=None, bits=bits, mode=mode,
+                                               with_cdf=(mode == "density"), huffman=True, want_values=True)
+                for (li, ti, p), r in zip(todo, res):
+                    batched[(li, ti)] = (r.values.view(p.shape), r.model)
+        for li, layer in enumerate(layers):
             quantized_weights_and_bias = []
             models = []
-            for params in layer.get_weights():
-                cdfs = None
-                if with_cumulative_weight_distribution:
-                    # the reference strips exact zeros with numpy.delete first (trainer.py:55-59);
-                    # the device kernels skip them instead -- same histogram, no compaction
-                    cdfs = utility.get_weight_distribution(params, skip_zeros=True)
-                quantized, model = utility.get_quantized_weight(params, bits=maximum_centroid_bits,
-                                                                mode=k_means_initialization_mode, cdfs=cdfs)
+            for ti, params in enumerate(layer.get_weights()):
+                if (li, ti) in batched:
+                    quantized, model = batched[(li, ti)]
+                else:
+                    cdfs = None
+                    if with_cumulative_weight_distribution:
+                        # the reference strips exact zeros with numpy.delete first (trainer.py:55-59);
+                        # the device kernels skip them instead -- same histogram, no compaction
+                        cdfs = utility.get_weight_distribution(params, skip_zeros=True)
+                    quantized, model = utility.get_quantized_weight(params, bits=maximum_centroid_bits,
+                                                                    mode=k_means_initialization_mode, cdfs=cdfs)
                 quantized_weights_and_bias.append(quantized)
                 models.append(model)
             layer.set_weights(quantized_weights_and_bias)

@@ -199,7 +199,7 @@ def kmeans_plusplus_init(x: torch.Tensor, k: int, stats=None):
     return x[ids].cpu().numpy(), ids.cpu().numpy()
 
 
-def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=None, arith="auto"):
+def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=None, arith="auto", reloc="auto"):
     """Replace every weight by the centroid of its k-means cluster (2**bits centroids;
     2**bits + 1 for ``density``).  Returns ``(quantized weights, fitted model)`` where the
     model exposes ``cluster_centers_``, ``labels_`` and ``n_iter_`` like the scikit-learn
@@ -213,7 +213,10 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=N
     ``group``: a torch.distributed process group when ``layer_weight`` is this rank's
     contiguous shard of a longer vector (shards start on multiples of 8192 elements).
     ``arith``: "auto" fits tensors of up to 4096 weights in scikit-learn's own summation order (kmeans.fit_reference: the
-    reference's centres bit for bit) and longer ones with exact fixed-point sums; "fixed" forces the latter."""
+    reference's centres bit for bit) and longer ones with exact fixed-point sums; "fixed" forces the latter.
+    ``reloc``: "auto" re-seeds empty clusters on the device (descending distance, ties by descending value); "reference" lets
+    ``numpy.argpartition`` pick the far samples from the distances in sample order, as scikit-learn does
+    (_k_means_common.pyx:186-187): the reference's own pairing and its own choice at a tie, for one host read per event."""
     n = int(np.prod(layer_weight.shape))
     if group is None and n < (2 ** bits) + 1:
         print("not enough bits:", n, " vs ", 2 ** bits)
@@ -227,13 +230,14 @@ def get_quantized_weight(layer_weight, bits=4, mode="linear", cdfs=None, group=N
         if group is not None:
             raise NotImplementedError("kmeans++ seeding needs the whole vector on one GPU")
         space, _ = kmeans_plusplus_init(x, 2 ** bits)
-        model, values = _kmeans.fit_vector(x, space, want_values=True, arith=arith)
+        model, values = _kmeans.fit_vector(x, space, want_values=True, arith=arith, **({"reloc": reloc} if reloc != "auto" else {}))
         shape = tuple(layer_weight.shape)
         return (values.cpu().numpy().reshape(shape), model) if was_numpy else (values.view(shape), model)
     if group is not None and mode != "density":
         raise NotImplementedError("sharded fits take an explicit init: use kmeans.DeviceKMeans")
     space = _init_space(x, n, bits, mode, cdfs)
-    model, values = _kmeans.fit_vector(x, np.asarray(space, dtype=np.float32), want_values=True, arith=arith, group=group)
+    model, values = _kmeans.fit_vector(x, np.asarray(space, dtype=np.float32), want_values=True, arith=arith, group=group,
+                                       **({"reloc": reloc} if reloc != "auto" else {}))
     shape = tuple(layer_weight.shape)
     if was_numpy:
         return values.cpu().numpy().reshape(shape), model

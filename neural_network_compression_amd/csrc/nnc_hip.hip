@@ -2888,6 +2888,10 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     if (rc) return rc;
     if (!centers_init_dev) return fail(NNC_EINVAL, "nnc_kmeans_init: null centers");
     if (ws_bytes < nnc_kmeans_workspace_bytes(p->k)) return fail(NNC_ENOSPACE, "nnc_kmeans_init: workspace too small");
+    // KMeans.fit refuses such input (sklearn/utils/validation.py: "Input X contains NaN" / "infinity"), and the kernels' searches
+    // and windows assume an ordered vector: a NaN anywhere in the data makes the NumPy mean NaN, an infinity the range infinite
+    if (!std::isfinite(p->x_mean) || !std::isfinite(p->tol) || !std::isfinite(p->lo) || !std::isfinite(p->hi))
+        return fail(NNC_EINVAL, "nnc_kmeans_init: Input X contains NaN or infinity (mean / variance / range of the data are not finite)");
     int glog2, rlog2;
     km_defaults(p, &glog2, &rlog2);
     // cells per unit, a hair under G / (hi - lo) so that x~ = hi still lands in the last cell
@@ -4039,13 +4043,19 @@ __device__ __forceinline__ void km_reloc_windows_body(const float *__restrict__ 
     __syncthreads();
     const int nwin = kt + 1;
     const int bad = (bnd[kt] != n) ? 1 : 0; // the counts must be those of this very vector
+    if (bad) { // (nothing below may trust the boundaries then: no window, no candidate, the selection reports the failure)
+        for (int j = tid; j < nwin; j += KM_THREADS) { KmWin w; w.start = 0; w.len = 0; w.off = 0; win[j] = w; }
+        if (tid == 0) { meta[0] = 0; meta[1] = nwin; meta[2] = 1; meta[3] = W; }
+        return;
+    }
     // Window j surrounds position bnd[j].  Each side starts at W samples and doubles until its
     // outermost sample has left the zone in which the float32 arg-min between the two
     // neighbouring centres is open (wide when two centres are close): the proof needs that.
     for (int j = tid; j < 2 * KM_THREADS; j += KM_THREADS) {
         long long st = 0, en = 0;
         if (j < nwin) {
-            const long long b = bnd[j];
+            long long b = bnd[j];
+            b = b < 0 ? 0 : (b > n ? n : b);
             long long wl = W, wr = W;
             if (j > 0 && j < kt && n > 0) {
                 const double zr = tab->zr[j - 1], zl = tab->zl[j];
@@ -4451,15 +4461,15 @@ static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmea
         int rc = km_ensure_cells(reinterpret_cast<KmWs *>(ws), p, 0, stream); // k_reloc_dist looks the candidates up in the cell table
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
                        reinterpret_cast<KmWs *>(ws), (int)window, (long long)cap,
-                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev), hist0);
+                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev), hist0, 0);
     LAUNCHCHK("k_reloc_windows");
     // a candidate costs its thread two dependent reads (window record, sample): one or two per thread, not a queue of them
     // (the windows double where centres are close, so there are about twice 2 * window * (k + 1) of them)
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (2 * (int64_t)window * (p->k + 1) + KM_THREADS - 1) / KM_THREADS));
-    hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
-                       reinterpret_cast<const int *>(meta_dev), cand_x, cand_d, (long long)cap, reinterpret_cast<const KmWs *>(ws), hist0);
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
+                       reinterpret_cast<const int *>(meta_dev), cand_x, cand_d, (long long)cap, reinterpret_cast<const KmWs *>(ws), hist0, 0);
     LAUNCHCHK("k_reloc_dist");
     return NNC_OK;
 }
@@ -4471,9 +4481,9 @@ extern "C" int nnc_kmeans_reloc_candidates(const float *x_sorted, void *ws, cons
     if (rc) return rc;
     if (!x_sorted || !cand_x_dev || !win_dev || !meta_dev || window < 1) return fail(NNC_EINVAL, "nnc_kmeans_reloc_candidates: bad argument");
     if (cap < 2 * (int64_t)window * (p->k + 1) || cap > 0x7FFFFFFF) return fail(NNC_ENOSPACE, "nnc_kmeans_reloc_candidates: cap must be in [2 * window * (k + 1), 2^31)");
-    hipLaunchKernelGGL(k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_windows, dim3(1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n,
                        reinterpret_cast<KmWs *>(ws), (int)window, (long long)cap,
-                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev));
+                       reinterpret_cast<KmWin *>(win_dev), reinterpret_cast<int *>(meta_dev), (unsigned *)nullptr, 0);
     LAUNCHCHK("k_reloc_windows");
     const int grid = (int)std::min<int64_t>(256, (cap + 16383) / 16384 + p->k / 4 + 1);
     hipLaunchKernelGGL(k_reloc_fill, dim3(grid), dim3(256), 0, S(stream), x_sorted, reinterpret_cast<const KmWin *>(win_dev),
@@ -4496,9 +4506,9 @@ extern "C" int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, co
 {
     if (!ws || !cand_x_dev || !cand_d_dev || !win_dev || !meta_dev || !keys_out_dev || n_empty < 1 || n_empty > NNC_KMAX)
         return fail(NNC_EINVAL, "nnc_kmeans_relocate_checked: bad argument");
-    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x_dev, cand_d_dev,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x_dev, cand_d_dev,
                        reinterpret_cast<const KmWin *>(win_dev), reinterpret_cast<const int *>(meta_dev), (int)n_empty,
-                       reinterpret_cast<long long *>(keys_out_dev), 1);
+                       reinterpret_cast<long long *>(keys_out_dev), 1, (const unsigned *)nullptr, 0);
     LAUNCHCHK("k_reloc_select");
     return NNC_OK;
 }
@@ -4543,9 +4553,9 @@ extern "C" int nnc_kmeans_relocate_windowed(const float *x_sorted, void *ws, con
     int64_t *keys = reinterpret_cast<int64_t *>(b); b += reloc_align(8 * (size_t)NNC_KMAX);
     unsigned *hist0 = reinterpret_cast<unsigned *>(b);
     if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, hist0, stream))) return rc;
-    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
                        reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
-                       reinterpret_cast<long long *>(keys), 1, hist0);
+                       reinterpret_cast<long long *>(keys), 1, (const unsigned *)hist0, 0);
     LAUNCHCHK("k_reloc_select");
     return km_launch_finalize(reinterpret_cast<KmWs *>(ws), p, FIN_FROM_PARTIALS, 1, stream);
 }
@@ -4574,15 +4584,15 @@ static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_reloc_dist), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         g_reloc_dist_attr[current_device()].store(1, std::memory_order_release);
     }
-    hipLaunchKernelGGL(k_reloc_head, dim3(KM_GMAX / KM_THREADS + 1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n, w, (long long)cap, win, meta,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_head, dim3(KM_GMAX / KM_THREADS + 1), dim3(KM_THREADS), 0, S(stream), x_sorted, (long long)p->n, w, (long long)cap, win, meta,
                        hist0, (int)wmax);
     LAUNCHCHK("k_reloc_head");
     // (sized for windows of 64, the common case: the kernel strides over whatever there is)
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(128, (2 * (int64_t)64 * (p->k + 1) + KM_THREADS - 1) / KM_THREADS));
-    hipLaunchKernelGGL(k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, win, meta, cand_x, cand_d, (long long)cap,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, (const KmWin *)win, (const int *)meta, cand_x, cand_d, (long long)cap,
                        reinterpret_cast<const KmWs *>(w), hist0, 1);
     LAUNCHCHK("k_reloc_dist");
-    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), w, cand_x, cand_d, win, meta, 0, keys, 1, hist0, 1);
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), w, (const float *)cand_x, (const float *)cand_d, (const KmWin *)win, (const int *)meta, 0, keys, 1, (const unsigned *)hist0, 1);
     LAUNCHCHK("k_reloc_select");
     return km_launch_finalize(w, p, FIN_FROM_PARTIALS, 2, stream, host_mapped, ticket);
 }
@@ -4606,7 +4616,7 @@ static int km_wait_ticket(volatile unsigned long long *word, unsigned long long 
     unsigned long long spins = 0;
     bool synced = false;
     auto t0 = std::chrono::steady_clock::now();
-    while (*word != ticket) {
+    while (__atomic_load_n(word, __ATOMIC_ACQUIRE) != ticket) { // (acquire: the payload the device wrote in front of the ticket is read after it)
         if ((++spins & 0x3FFF) == 0) {
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             if (el > 0.02 && !synced) { // a non-coherent mapping, or a device error: make the write visible / surface the error
@@ -4734,9 +4744,9 @@ extern "C" int nnc_kmeans_reloc_select_local(const float *x_sorted, void *ws, co
     int32_t *meta = reinterpret_cast<int32_t *>(b); b += reloc_align(16) + reloc_align(8 * (size_t)NNC_KMAX);
     unsigned *hist0 = reinterpret_cast<unsigned *>(b);
     if ((rc = km_reloc_windows_dist(x_sorted, ws, p, window, cand_x, cand_d, cap, win, meta, hist0, stream))) return rc;
-    hipLaunchKernelGGL(k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
+    NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<KmWs *>(ws), cand_x, cand_d,
                        reinterpret_cast<const KmWin *>(win), reinterpret_cast<const int *>(meta), (int)n_empty,
-                       reinterpret_cast<long long *>(keys_out_dev), 0, hist0);
+                       reinterpret_cast<long long *>(keys_out_dev), 0, (const unsigned *)hist0, 0);
     LAUNCHCHK("k_reloc_select");
     return NNC_OK;
 }
@@ -4908,6 +4918,10 @@ static int rccl_load()
     } while (0)
 
 struct NncComm { ncclComm_t comm; int rank, world; };
+
+// NNC_OK if librccl can be bound in this process (nothing is created): every rank asks before any of them enters
+// nnc_comm_init, which blocks until all ranks have entered it.
+extern "C" int nnc_comm_available(void) { return rccl_load(); }
 
 extern "C" int nnc_comm_unique_id(void *id_out, size_t len)
 {

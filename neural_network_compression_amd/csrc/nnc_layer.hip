@@ -19,6 +19,8 @@
 int nnc_set_error_(int code, const char *msg); // in nnc_hip.hip
 int nnc_publish_bytes_(const void *src_dev, void *dst_host_mapped, int nbytes, void *host_ticket, uint64_t ticket, void *stream);
 int nnc_wait_ticket_(void *host_ticket, uint64_t ticket, void *stream);
+int nnc_sort_pruned_bounded_flagged_(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float vmin, float vmax, float thr,
+                                     float *sorted_out, void *ws, size_t ws_bytes, int32_t *flag_dev, void *stream); // in nnc_sort.hip
 
 // --------------------------------------------------------------------------------------
 // host arithmetic, NumPy's way
@@ -277,6 +279,14 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         const int back_bytes = (int)al((size_t)k * 12) + 32;
         LCHK(read_back(back, hb + 1024, back_bytes));
         const int32_t *h_res = reinterpret_cast<const int32_t *>(hb + 1024 + al((size_t)k * 12));
+        {
+            const float *h_resf = reinterpret_cast<const float *>(h_res); // (RefOut: six int32, then x_mean, tol)
+            if (!std::isfinite(h_resf[6]) || !std::isfinite(h_resf[7])) { // NaN / infinity in the tensor: the caller's own path raises, as KMeans.fit does
+                if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
+                res->status = NNC_LAYER_HOST;
+                return NNC_OK;
+            }
+        }
         res->n_iter = h_res[0]; res->stop = h_res[1]; res->n_relocations = h_res[2]; res->reloc_ties = h_res[3]; res->reloc_multi = h_res[4];
         res->arith = NNC_ARITH_REFERENCE;
     } else {
@@ -291,16 +301,27 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         LCHK(side_stream(&side));
         LHIP(hipEventRecord(side->fork, s));
         LHIP(hipStreamWaitEvent(side->stream, side->fork, 0));
+        // From here on work is in flight on the second stream, writing into the caller's workspace: every way out of this scope --
+        // an error return included -- first makes the caller's stream wait for it (and, on an error, waits itself), so that the
+        // caller may drop the workspace as soon as the call is back.
+        struct SideJoin {
+            SideStream *side; hipStream_t s; bool joined = false;
+            ~SideJoin() { if (!joined) { (void)hipEventRecord(side->join, side->stream); (void)hipStreamWaitEvent(s, side->join, 0); (void)hipStreamSynchronize(s); } }
+        } side_join{side, s};
         LCHK(nnc_chunk_sums_f32(x, n, 0, nullptr, c1, side->stream));
         LCHK(nnc_fold_f32(c1, nch, n, NNC_FOLD_MEAN, nullptr, out6, side->stream));           // [0] = mean
         LCHK(nnc_chunk_sums_f32(x, n, 1, out6, c2, side->stream));
         LCHK(nnc_fold_f32(c2, nch, n, NNC_FOLD_MEAN, nullptr, out6 + 1, side->stream));       // [1] = variance
         LHIP(hipEventRecord(side->join, side->stream));
         float *xs = reinterpret_cast<float *>(wb + L.sorted);
+        int32_t *oob_d = reinterpret_cast<int32_t *>(wb + L.stats_out + 336); // the bounded sort's verdict: a weight outside the bounds it was given
+        const int32_t *h_oob = reinterpret_cast<const int32_t *>(hb + 512 + 336);
+        bool bounded = false;
         // (a pruned tensor whose threshold is known: the surviving weights span few key bits -- three radix passes instead of four)
-        if (4 * n_zero >= n && lp->prune && nnc_sort_pruned_bounded_bits(xmin, xmax, h_prune[1], n_neg, n - n_neg - n_zero) > 0)
-            LCHK(nnc_sort_pruned_bounded_f32(x, n, n_neg, n_zero, xmin, xmax, h_prune[1], xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
-        else if (4 * n_zero >= n) LCHK(nnc_sort_pruned_f32(x, n, n_neg, n_zero, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
+        if (4 * n_zero >= n && lp->prune && nnc_sort_pruned_bounded_bits(xmin, xmax, h_prune[1], n_neg, n - n_neg - n_zero) > 0) {
+            LCHK(nnc_sort_pruned_bounded_flagged_(x, n, n_neg, n_zero, xmin, xmax, h_prune[1], xs, wb + L.sort_ws, L.sort_ws_bytes, oob_d, stream));
+            bounded = true;
+        } else if (4 * n_zero >= n) LCHK(nnc_sort_pruned_f32(x, n, n_neg, n_zero, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
         else LCHK(nnc_sort_f32(x, n, xs, wb + L.sort_ws, L.sort_ws_bytes, stream));
         const bool with_prefix = (reinterpret_cast<uintptr_t>(xs) & 15) == 0;
         int64_t *ranks_d = reinterpret_cast<int64_t *>(wb + L.stats_out + 64);
@@ -310,6 +331,7 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
             if (!std::isfinite(min_nz)) { // no non-zero weight: the reference's numpy call raises; so does the caller's own path
                 LHIP(hipStreamWaitEvent(s, side->join, 0));
                 LHIP(hipStreamSynchronize(s));
+                side_join.joined = true;
                 if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
                 res->status = NNC_LAYER_HOST;
                 return NNC_OK;
@@ -320,7 +342,21 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         }
         // ---- the second read: mean, variance (and the ranks)
         LHIP(hipStreamWaitEvent(s, side->join, 0));
-        LCHK(read_back(out6, hb + 512, 64 + 33 * 8));
+        side_join.joined = true;
+        LCHK(read_back(out6, hb + 512, 64 + 33 * 8 + 16));
+        if (!std::isfinite(h_f[0]) || !std::isfinite(h_f[1]) || !std::isfinite(xmin) || !std::isfinite(xmax)) {
+            // a NaN or an infinity in the tensor: KMeans.fit raises on such input, and so does the caller's own path (from the pruned tensor)
+            if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
+            res->status = NNC_LAYER_HOST;
+            return NNC_OK;
+        }
+        if (bounded && *h_oob) {
+            // a weight outside [min, -threshold] u {0} u [threshold, max] -- a NaN, the statistics pass ignores those: the compact-key
+            // sort clamped it, so the sorted copy is not the tensor's.  The step-by-step path (general sorts) goes on from here.
+            if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
+            res->status = NNC_LAYER_HOST;
+            return NNC_OK;
+        }
         const float mean = h_f[0], var = h_f[1];
         // ---- k-means parameters (KMeans.fit's tolerance and centring, _kmeans.py:279-287, 1479-1484; the fixed-point rule)
         nnc_kmeans_params p;

@@ -215,9 +215,13 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_keys(const float *__res
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     const long long nvec = vec ? (n >> 2) : 0;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    // (a value outside the caller's bounds -- or a NaN, which is neither below zero nor inside the positive range -- is clamped so
+    // that nothing is written out of range, and reported: the sorted vector then holds values that are not in the input)
+    bool outside = false;
     auto key_of = [&](float e) -> unsigned {
         const unsigned o = f32_ord(e);
-        if (e < 0.0f) { const unsigned c = o < bd.lo_neg ? bd.lo_neg : (o > bd.hi_neg ? bd.hi_neg : o); return c - bd.lo_neg; }
+        if (e < 0.0f) { outside |= (o < bd.lo_neg) | (o > bd.hi_neg); const unsigned c = o < bd.lo_neg ? bd.lo_neg : (o > bd.hi_neg ? bd.hi_neg : o); return c - bd.lo_neg; }
+        outside |= (o < bd.lo_pos) | (o > bd.hi_pos);
         const unsigned c = o < bd.lo_pos ? bd.lo_pos : (o > bd.hi_pos ? bd.hi_pos : o);
         return bd.span_neg + (c - bd.lo_pos);
     };
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(SPLIT_THREADS) void k_split_keys(const float *__res
             if (nzv && at < cap) keys[at] = key_of(e);
         }
     }
+    if (outside) atomicOr(counter + 1, 1ull);
 }
 
 // every workgroup owns the contiguous range [b * chunk, (b + 1) * chunk) of the keys; table[d * nblk + b] = its keys with digit d
@@ -412,8 +417,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const unsigned *__res
 
 // sorted compact keys -> the sorted vector: negatives, the zeros, positives
 __global__ __launch_bounds__(256) void k_rs_assemble(const unsigned *__restrict__ keys, long long n, long long n_neg, long long n_zero,
-                                                     float *__restrict__ out, RsBounds bd)
+                                                     float *__restrict__ out, RsBounds bd, const unsigned long long *__restrict__ counter,
+                                                     int *__restrict__ flag_out)
 {
+    if (flag_out && blockIdx.x == 0 && threadIdx.x == 0) *flag_out = counter[1] != 0ull; // (k_split_keys met a value outside the bounds)
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         float v;
@@ -469,8 +476,27 @@ extern "C" size_t nnc_sort_pruned_bounded_workspace_bytes(int64_t n_nz)
     return 2 * al256((size_t)n_nz * 4 + 16) + al256(8) + al256((size_t)RS_MAXR * RS_MAXBLOCKS * 4) + al256(RS_MAXR * 4) + 256;
 }
 
+int nnc_sort_pruned_bounded_flagged_(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float vmin, float vmax, float thr,
+                                     float *sorted_out, void *ws, size_t ws_bytes, int32_t *flag_dev, void *stream);
 extern "C" int nnc_sort_pruned_bounded_f32(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float vmin, float vmax, float thr,
                                            float *sorted_out, void *ws, size_t ws_bytes, void *stream)
+{
+    return nnc_sort_pruned_bounded_flagged_(x, n, n_neg, n_zero, vmin, vmax, thr, sorted_out, ws, ws_bytes, nullptr, stream);
+}
+
+static unsigned char *rs_ws_base(void *ws) { return reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255); }
+
+// device int32 inside the workspace: non-zero after the sort iff a weight lay outside [vmin, -thr] u {0} u [thr, vmax] (or was NaN)
+extern "C" const int32_t *nnc_sort_pruned_bounded_flag(void *ws, int64_t n_nonzero)
+{
+    if (!ws || n_nonzero < 0) return nullptr;
+    unsigned char *b = rs_ws_base(ws) + 2 * al256((size_t)n_nonzero * 4 + 16);
+    return reinterpret_cast<const int32_t *>(b + 8); // (the low half of the 64-bit word behind the counter)
+}
+
+// (flag_dev: where the verdict goes as well -- the layer call keeps it next to the scalars it reads back anyway)
+int nnc_sort_pruned_bounded_flagged_(const float *x, int64_t n, int64_t n_neg, int64_t n_zero, float vmin, float vmax, float thr,
+                                     float *sorted_out, void *ws, size_t ws_bytes, int32_t *flag_dev, void *stream)
 {
     if (n < 0 || n_neg < 0 || n_zero < 0 || n_neg + n_zero > n || n >= ((int64_t)1 << 31) || (n > 0 && (!x || !sorted_out)))
         return nnc_set_error_(NNC_EINVAL, "nnc_sort_pruned_bounded_f32: bad argument");
@@ -485,10 +511,10 @@ extern "C" int nnc_sort_pruned_bounded_f32(const float *x, int64_t n, int64_t n_
     unsigned char *b = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws) + 255) & ~(uintptr_t)255);
     unsigned *ka = reinterpret_cast<unsigned *>(b); b += al256((size_t)n_nz * 4 + 16);
     unsigned *kb = reinterpret_cast<unsigned *>(b); b += al256((size_t)n_nz * 4 + 16);
-    unsigned long long *counter = reinterpret_cast<unsigned long long *>(b); b += al256(8);
+    unsigned long long *counter = reinterpret_cast<unsigned long long *>(b); b += al256(16); // [0] keys written, [1] a value outside the bounds
     unsigned *table = reinterpret_cast<unsigned *>(b); b += al256((size_t)RS_MAXR * RS_MAXBLOCKS * 4);
     unsigned *totals = reinterpret_cast<unsigned *>(b);
-    hipError_t e = hipMemsetAsync(counter, 0, sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(counter, 0, 2 * sizeof(unsigned long long), s);
     if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     if (n_nz > 0) {
         const long long tiles = (n / 4 + 4 * SPLIT_THREADS - 1) / (4 * SPLIT_THREADS);
@@ -512,7 +538,7 @@ extern "C" int nnc_sort_pruned_bounded_f32(const float *x, int64_t n, int64_t n_
     }
     {
         const int grid = (int)std::min<long long>((n + 1023) / 1024, 2048);
-        hipLaunchKernelGGL(k_rs_assemble, dim3(std::max(grid, 1)), dim3(256), 0, s, ka, (long long)n, (long long)n_neg, (long long)n_zero, sorted_out, bd);
+        hipLaunchKernelGGL(k_rs_assemble, dim3(std::max(grid, 1)), dim3(256), 0, s, ka, (long long)n, (long long)n_neg, (long long)n_zero, sorted_out, bd, (const unsigned long long *)counter, (int *)flag_dev);
         if ((e = hipGetLastError()) != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     }
     return NNC_OK;

@@ -209,6 +209,8 @@ def fit_reference(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = 
     hostb = blk.cpu().numpy()
     host = hostb[8 * k:].view(np.float32)
     res = host[kp: kp + 8].view(np.int32)
+    if not (np.isfinite(host[kp + 6]) and np.isfinite(host[kp + 7])):   # the kernel's own mean / tolerance of the data
+        raise ValueError("Input X contains NaN or infinity.")            # (KMeans.fit's input validation)
     model = QuantizedModel(host[:k].copy(), lab, int(res[0]), int(res[2]), {1: "tol", 2: "max_iter", 3: "strict"}.get(int(res[1]), "?"))
     model.counts_device_ = counts
     model.counts_host_ = hostb[: 8 * k].view(np.int64).copy()
@@ -227,6 +229,8 @@ def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "au
     if arith not in ("auto", "reference", "fixed"):
         raise ValueError("arith must be 'auto', 'reference' or 'fixed'")
     k = int(np.asarray(init).size)
+    if kw.get("reloc") == "reference" and arith == "auto":
+        arith = "fixed"   # (the one-launch fit of a short tensor re-seeds on chip: NumPy's own selection needs the host in the loop)
     if arith == "reference" or (arith == "auto" and reference_fit_applies(x.numel(), k, group)):
         if group is not None:
             raise ValueError("arith='reference' is a single-GPU fit")
@@ -284,6 +288,9 @@ class DeviceKMeans:
             stats = LayerStats(x, n_total, group)
         self.stats = stats
         mean, var, xmin, xmax = stats.mean, stats.var, stats.min, stats.max
+        if not (np.isfinite(mean) and np.isfinite(var) and np.isfinite(xmin) and np.isfinite(xmax)):
+            # KMeans.fit's input validation (sklearn/utils/validation.py, reached from utility.py:238): no NaN, no infinity
+            raise ValueError("Input X contains NaN or infinity.")
         self.n_negative, self.n_zero = stats.n_negative, stats.n_zero
         self.x_mean = mean
         self.tol_ = np.float32(var * np.float32(tol))  # np.mean(np.var(X, axis=0)) * tol, float32
@@ -309,8 +316,10 @@ class DeviceKMeans:
         self.n_reloc_windowed = 0   # relocation events settled by the windowed selection
         self.n_reloc_full = 0       # ... by the full distance pass
         self._reloc_scratch = None
-        if reloc not in ("auto", "full"):
-            raise ValueError("reloc must be 'auto' or 'full'")
+        if reloc not in ("auto", "full", "reference"):
+            raise ValueError("reloc must be 'auto', 'full' or 'reference'")
+        if reloc == "reference" and group is not None:
+            raise ValueError("reloc='reference' (NumPy's own selection on the host) is a single-GPU option")
         self.reloc = reloc
         # pinned host landing zones for the small device->host reads (status block, 4096-bin histogram)
         # two slots of (status block, ticket): a look-in alternates between them, so that one may still be in flight
@@ -548,6 +557,9 @@ class DeviceKMeans:
         defined (CPU-dispatch dependent) pairing otherwise."""
         n_empty = int(st.n_empty)
         strict_check = st.iter >= 1 and st.same_counts
+        if self.reloc == "reference":
+            self._relocate_like_numpy(st, n_empty, strict_check)
+            return
         if (self.reloc == "auto" and self.sorted_everywhere and int(st.paused) == 1 and not strict_check
                 and self._relocate_windowed(n_empty)):
             self.n_relocations += 1
@@ -588,6 +600,37 @@ class DeviceKMeans:
         if flag is not None:
             nat.check(self.L.nnc_kmeans_set_done_if(self.ws.data_ptr(), flag.data_ptr(), 3, self.stream))
         self.n_relocations += 1
+
+    def _relocate_like_numpy(self, st, n_empty: int, strict_check: bool) -> None:
+        """The event exactly as scikit-learn runs it (_k_means_common.pyx:167-211): the float32 squared distances of ALL samples to
+        their own centre, in SAMPLE order, go to the host and ``numpy.argpartition(distances, -n_empty)[:-n_empty-1:-1]`` picks the far
+        samples -- which ones at a tie at the cut, and which of them goes to which empty cluster, is whatever NumPy's introselect
+        leaves, and the reference inherits exactly that.  The device's own rule (descending distance, ties by descending value)
+        agrees on 69 of the 70 golden fits; this option is for the callers who want the 70th as well: one read of 4 bytes per
+        weight per event (events are rare), everything else stays on the device."""
+        lab = prev = None
+        _, _, d = self._assign_on(self.x, which=0, labels=False, distances=True)
+        flag = None
+        if strict_check:
+            lab, _, _ = self._assign_on(self.x, which=0, labels=True)
+            prev, _, _ = self._assign_on(self.x, which=1, labels=True)
+            flag = torch.empty(1, dtype=torch.int32, device=self.dev)
+            nat.check(self.L.nnc_labels_equal(lab.data_ptr(), prev.data_ptr(), self.n, 1 if self.k <= 256 else 2, flag.data_ptr(), self.stream))
+        dh = d.cpu().numpy()
+        far = np.argpartition(dh, -n_empty)[:-n_empty - 1:-1]
+        xh = self.x[torch.from_numpy(far.astype(np.int64)).to(self.dev)].cpu().numpy()
+        db = dh[far].view(np.uint32).astype(np.int64)
+        if float(dh.max()) == 0.0:
+            db[:] = 0                                   # np.max(distances) == 0: nothing is relocated (the kernel reads it off the first key)
+        xb = xh.view(np.uint32).astype(np.int64)
+        ordered = np.where(xb & 0x80000000, (~xb) & 0xFFFFFFFF, xb | 0x80000000)
+        keys = torch.from_numpy(((db << 32) | ordered).astype(np.int64)).to(self.dev)
+        nat.check(self.L.nnc_kmeans_relocate(self.ws.data_ptr(), keys.data_ptr(), int(keys.numel()), self.stream))
+        nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 1, self.stream))
+        if flag is not None:
+            nat.check(self.L.nnc_kmeans_set_done_if(self.ws.data_ptr(), flag.data_ptr(), 3, self.stream))
+        self.n_relocations += 1
+        self.n_reloc_full += 1
 
     # -------------------------------------------------------------- the fit loop
     def fit(self, want_values: bool = True):

@@ -95,11 +95,22 @@ class RcclComm:
         self.group = group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         torch.cuda.set_device(device)
-        buf = (ctypes.c_ubyte * 128)()
-        if self.rank == 0:
-            nat.check(self.L.nnc_comm_unique_id(buf, 128))
+        self.handle = None
         backend = dist.get_backend(group)
-        idt = torch.tensor(list(buf), dtype=torch.uint8, device=device if backend == "nccl" else "cpu")
+        cdev = device if backend == "nccl" else "cpu"
+        # ncclCommInitRank blocks until every rank has entered it: the ranks first agree, over the caller's group, that all of them
+        # can bind librccl and that rank 0 has an id to hand out -- a rank that cannot raises here, together with all the others,
+        # instead of leaving them inside the init for ever
+        buf = (ctypes.c_ubyte * 128)()
+        ok = 1 if self.L.nnc_comm_available() == 0 else 0
+        why = "" if ok else self.L.nnc_last_error().decode("utf-8", "replace")
+        if ok and self.rank == 0 and self.L.nnc_comm_unique_id(buf, 128) != 0:
+            ok, why = 0, self.L.nnc_last_error().decode("utf-8", "replace")
+        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 0:
+            raise nat.NativeLibraryError("the library's RCCL communicator cannot be created on every rank" + (f" (rank {self.rank}: {why})" if why else ""))
+        idt = torch.tensor(list(buf), dtype=torch.uint8, device=cdev)
         dist.broadcast(idt, src=dist.get_global_rank(group, 0), group=group)
         raw = bytes(idt.cpu().tolist())
         idbuf = ctypes.create_string_buffer(raw, 128)

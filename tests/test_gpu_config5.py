@@ -26,7 +26,7 @@ def test_gpt2_small_layer_list_full_pipeline():
     tensors = []
     for i, (name, shape) in enumerate(layers):
         w = synth.weights(shape, 5000 + i)
-        if name in ("h0.b_proj", "h0.ln1", "h0.b_attn", "h0.b_fc", "h3.ln2", "wte"):
+        if name in ("h0.b_proj", "h0.ln1", "h0.b_attn", "h0.b_fc", "h3.ln2", "wte", "h5.mlp.c_fc", "h7.attn.c_attn"):
             host[name] = w
         tensors.append((name, torch.from_numpy(w).cuda()))
     total = sum(t.numel() for _, t in tensors)
@@ -88,6 +88,19 @@ def test_gpt2_small_layer_list_full_pipeline():
         assert r.model.n_iter_ == ob.n_iter_, (name, r.model.n_iter_, ob.n_iter_)
         assert np.array_equal(r.model.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), name
         assert np.array_equal(r.model.labels_, ob.labels_), name
+
+    # ---- one 768 x 3072 and one 768 x 2304 matrix (the sizes that carry the workload) against the oracle's exact-integer sums, bit for bit
+    for name in ("h5.mlp.c_fc", "h7.attn.c_attn"):
+        w = host[name].copy()
+        omask = orc.prune_weigth(w, 1.0, True)
+        ob = orc.kmeans_lloyd(w.ravel(), orc.init_space(w, 4, "linear"), accum="B")
+        r = res[name]
+        assert np.array_equal(r.mask.cpu().numpy().astype(bool).ravel(), omask.ravel()), name
+        assert r.model.n_iter_ == ob.n_iter_, (name, r.model.n_iter_, ob.n_iter_)
+        assert np.array_equal(r.model.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), name
+        assert np.array_equal(r.model.labels_, ob.labels_), name
+        ol, _, ot = orc.huffman_lengths(np.bincount(ob.labels_, minlength=16))
+        assert np.array_equal(r.code_lengths, ol) and r.total_bits == ot, name
 
     # ---- the 38.6 M-weight embedding: centroid indices of a sample against the brute-force float32 arg-min over all 16 centres
     w = host["wte"].copy().ravel()

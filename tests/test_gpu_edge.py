@@ -319,3 +319,49 @@ def test_bounded_sort_of_a_pruned_vector(km_mod, n):
     assert L.nnc_sort_pruned_bounded_bits(-1.0, 1.0, 0.0, 5, 5) == 0
     assert L.nnc_sort_pruned_bounded_bits(-1.0, 1.0, 1e-30, 5, 5) == 0
     assert L.nnc_sort_pruned_bounded_bits(-0.5, 0.5, 0.06, 5, 5) == 26
+
+
+def test_bounded_sort_reports_weights_outside_its_bounds(km_mod):
+    """nnc_sort_pruned_bounded_f32 clamps a weight outside the bounds it was given (or a NaN) instead of writing out of range, and
+    says so in the flag word of its workspace; with honest bounds the flag stays 0.  nnc_compress_layer_f32 reads the flag and hands
+    such a tensor (a NaN weight: the statistics pass ignores it) to the step-by-step path instead of fitting a sorted copy that is
+    not the tensor's."""
+    import ctypes
+    from neural_network_compression_amd import _native as nat, pipeline
+
+    _, ops = km_mod
+    L = nat.load()
+    n = 70_001
+    w = synth.weights((n,), 8801)
+    x = torch.from_numpy(w.copy()).cuda()
+    mask, stats, nz, mm, signs = ops.prune_stats_(x, 1.0, True)
+    thr = float(stats.cpu().numpy()[1])
+    mmh, sg = mm.cpu().numpy(), signs.cpu().numpy()
+    n_neg, n_zero = int(sg[0]), int(sg[1])
+    stream = torch.cuda.current_stream().cuda_stream
+    wsb = int(L.nnc_sort_pruned_bounded_workspace_bytes(n - n_zero))
+    for vmax, want_flag in ((float(mmh[1]), 0), (float(mmh[1]) * 0.5, 1)):   # honest bounds; an upper bound that half the tail exceeds
+        ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
+        out = torch.empty_like(x)
+        nat.check(L.nnc_sort_pruned_bounded_f32(x.data_ptr(), n, n_neg, n_zero, float(mmh[0]), vmax, thr, out.data_ptr(), ws.data_ptr(), wsb, stream))
+        torch.cuda.synchronize()
+        addr = L.nnc_sort_pruned_bounded_flag(ws.data_ptr(), n - n_zero)
+        off = addr - ws.data_ptr()
+        flag = int(ws[off: off + 4].view(torch.int32).item())
+        assert (flag != 0) == bool(want_flag), (vmax, flag)
+        if not want_flag:
+            assert torch.equal(out, torch.sort(x).values)
+    # a NaN (or an infinite) weight: the statistics pass ignores a NaN for min / max, so the compact-key sort would clamp it -- the
+    # layer call notices (flag, non-finite mean) and hands the tensor back; the fit then refuses it as KMeans.fit does
+    # (sklearn's input validation: ValueError), on the one-call path and on the step-by-step path alike, long and short tensors
+    for n_, bad in ((200_000, np.nan), (200_000, np.inf), (3000, np.nan)):
+        wn = synth.weights((n_,), 8802)
+        wn[n_ // 3] = bad
+        for native in (True, False):
+            with pytest.raises(ValueError, match="NaN or infinity"):
+                pipeline.compress_layer(torch.from_numpy(wn.copy()).cuda(), q=1.0, bits=4, mode="linear", native=native)
+    from neural_network_compression_amd.common import utility
+    with pytest.raises(ValueError, match="NaN or infinity"):
+        wn = synth.weights((50_000,), 8803)
+        wn[7] = np.nan
+        utility.get_quantized_weight(wn, bits=4, mode="linear")
