@@ -556,6 +556,18 @@ size_t nnc_kmeans_reloc_scratch_bytes_sharded(int32_t k, int32_t window, int32_t
 int nnc_merge_keys(const int64_t *lists_dev, int32_t nlists, int32_t per, int64_t *out_dev, int32_t m, void *stream);
 int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
                                          void *scratch_dev, size_t scratch_bytes, void *stream);
+/* nnc_kmeans_fit for a sharded vector: the whole Lloyd loop of KMeans.fit (sklearn/cluster/_kmeans.py:624-752, reached from
+ * neural_network_compression/common/utility.py:237-238) as ONE call per rank -- batches of nnc_kmeans_iterate_sharded, the look-ins,
+ * batch sizing from the decay of the centre shift, and nnc_kmeans_relocate_windowed_sharded for the empty-cluster events it
+ * applies to; no host language between two launches, so N ranks do not pay an interpreter round trip per batch or per event.
+ * Every rank makes the same call; the status is the same on every rank after each iteration, so every rank takes the same
+ * decisions.  n_min = the length of the SHORTEST shard (the applicability of the windowed relocation must come out alike
+ * everywhere).  Other arguments as in nnc_kmeans_fit; reloc_scratch: nnc_kmeans_reloc_scratch_bytes_sharded(k, window, world)
+ * bytes.  Returns with status_out->done != 0, or with status_out->paused != 0 when the caller has to run the full-pass
+ * relocation / strict-convergence check (then call again).  *n_windowed_out = windowed events this call asked for. */
+int nnc_kmeans_fit_sharded(void *comm, const float *x_iter, void *ws, const nnc_kmeans_params *p, int64_t n_min, int32_t max_batch,
+                           int32_t sorted, void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped,
+                           uint64_t *ticket_io, nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Measurement aid (used by bench.py): HIP events around the launches of the data-touching kernels, recorded on the

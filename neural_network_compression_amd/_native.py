@@ -112,6 +112,8 @@ SIGNATURES = {
     "nnc_kmeans_iterate_publish": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_void_p, ctypes.c_uint64, c_void_p]),
     "nnc_kmeans_fit": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_i32, c_i32, c_void_p, c_size, c_void_p,
                                ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(KMeansStatus), ctypes.POINTER(c_i32), c_void_p]),
+    "nnc_kmeans_fit_sharded": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(KMeansParams), ctypes.c_int64, c_i32, c_i32, c_void_p, c_size,
+                                       c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(KMeansStatus), ctypes.POINTER(c_i32), c_void_p]),
     "nnc_kmeans_set_done": (c_int, [c_void_p, c_i32, c_void_p]),
     "nnc_kmeans_label_counts": (c_int, [c_void_p, c_void_p, ctypes.POINTER(KMeansParams), c_int, c_void_p, c_void_p]),
     "nnc_kmeans_get_centers": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),

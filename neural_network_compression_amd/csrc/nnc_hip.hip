@@ -327,15 +327,26 @@ __global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks,
         for (int i = threadIdx.x; i < len; i += 1024) buf[i] = chunks[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
+            // the adds form one dependent chain; the LDS reads must not sit in it: the next 32 values are in flight (registers
+            // nb[]) while the current 32 (cb[]) are folded
             const float4 *b4 = reinterpret_cast<const float4 *>(buf);
             const int nq = len >> 2;
             int qd = 0;
-            for (; qd + 8 <= nq; qd += 8) {
-                float4 v[8];
+            if (nq >= 8) {
+                float4 cb[8], nb[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = b4[qd + u];
+                for (int u = 0; u < 8; u++) cb[u] = b4[u];
+                for (; qd + 16 <= nq; qd += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) { acc = acc + v[u].x; acc = acc + v[u].y; acc = acc + v[u].z; acc = acc + v[u].w; }
+                    for (int u = 0; u < 8; u++) nb[u] = b4[qd + 8 + u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { acc = acc + cb[u].x; acc = acc + cb[u].y; acc = acc + cb[u].z; acc = acc + cb[u].w; }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) cb[u] = nb[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { acc = acc + cb[u].x; acc = acc + cb[u].y; acc = acc + cb[u].z; acc = acc + cb[u].w; }
+                qd += 8;
             }
             for (; qd < nq; qd++) { const float4 v = b4[qd]; acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w; }
             for (int i = nq << 2; i < len; i++) acc = acc + buf[i];
@@ -5076,4 +5087,62 @@ extern "C" int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_s
     if ((rc = nnc_merge_keys(reinterpret_cast<const int64_t *>(all), c->world, per, reinterpret_cast<int64_t *>(merged), per, stream))) return rc;
     if ((rc = nnc_kmeans_relocate_if_proven(ws, reinterpret_cast<const int64_t *>(merged), per, stream))) return rc;
     return km_launch_finalize(w, p, FIN_FROM_PARTIALS, 1, stream);
+}
+
+// The Lloyd loop of a SHARDED fit as one call (what nnc_kmeans_fit is to the single GPU): batches of iterations with the all-reduce
+// inside (nnc_kmeans_iterate_sharded), the look-ins, batch sizing from the decay of the centre shift, and the windowed relocation of
+// empty clusters with its collectives (nnc_kmeans_relocate_windowed_sharded) -- no host language between two launches.  Every rank
+// makes the same call; the state machine is replicated (the status is the same on every rank after each finalize), so every rank
+// takes the same decisions.  n_min = the shortest shard: whether the windowed relocation applies must come out alike everywhere
+// (the window itself depends on n_empty only).  Comes back when the fit has stopped or needs what only the caller can do
+// (full-pass relocation, strict-convergence check: status.paused != 0).
+// No relocation chain "in case" behind the iterations here: it would put two more collectives behind every one of them.
+extern "C" int nnc_kmeans_fit_sharded(void *comm, const float *x_iter, void *ws, const nnc_kmeans_params *pp, int64_t n_min, int32_t max_batch,
+                                      int32_t sorted, void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped,
+                                      uint64_t *ticket_io, nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream)
+{
+    int rc = km_check(ws, pp, "nnc_kmeans_fit_sharded");
+    if (rc) return rc;
+    if (!comm) return fail(NNC_EINVAL, "nnc_kmeans_fit_sharded: null communicator");
+    if (!host_mapped || !ticket_io || !status_out || (reinterpret_cast<uintptr_t>(host_mapped) & 7) != 0) return fail(NNC_EINVAL, "nnc_kmeans_fit_sharded: null / unaligned pointer");
+    const nnc_kmeans_params p = *pp;
+    if (n_min < 0 || n_min > p.n) return fail(NNC_EINVAL, "nnc_kmeans_fit_sharded: n_min is the shortest shard (0 <= n_min <= n)");
+    if (max_batch < 1) max_batch = 1;
+    const int world = reinterpret_cast<NncComm *>(comm)->world;
+    const size_t slot = sizeof(nnc_kmeans_status) + 8;
+    unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped); // two slots, used alternately
+    int batch = 1; // the first iteration is where duplicate initial centres surface as empty clusters
+    int nwin = 0;
+    double s_prev = -1.0, s_last = -1.0;
+    int i_prev = 0, i_last = 0;
+    for (;;) {
+        const uint64_t ticket = ++(*ticket_io);
+        unsigned char *sl = hb + (ticket & 1) * slot;
+        if ((rc = nnc_kmeans_iterate_sharded(comm, x_iter, ws, &p, batch, sl, ticket, stream))) return rc;
+        if ((rc = km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(sl + sizeof(nnc_kmeans_status)), ticket, S(stream)))) return rc;
+        const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
+        *status_out = st;
+        if (st.done) break;
+        if (st.paused) {
+            const bool strict_check = st.iter >= 1 && st.same_counts;
+            const int32_t window = (sorted && st.paused == 1 && !strict_check) ? nnc_kmeans_reloc_window(n_min, st.n_empty) : 0;
+            if (window == 0 || !reloc_scratch_dev || reloc_scratch_bytes < nnc_kmeans_reloc_scratch_bytes_sharded(p.k, window, world)) break; // the caller's turn
+            if ((rc = nnc_kmeans_relocate_windowed_sharded(comm, x_iter, ws, &p, st.n_empty, reloc_scratch_dev, reloc_scratch_bytes, stream))) return rc;
+            nwin++; // (an unproven selection comes back as paused == 2 with the next look-in, and the caller takes this one back)
+            batch = 1;
+            s_prev = s_last = -1.0;
+            continue;
+        }
+        // size the next batch so that it ends about where the shift crosses the tolerance (as nnc_kmeans_fit does)
+        s_prev = s_last; i_prev = i_last;
+        s_last = (double)st.shift_tot; i_last = st.iter;
+        batch = std::min(max_batch, batch * 2);
+        if (s_prev > 0.0 && s_last > 0.0 && s_prev > s_last && p.tol > 0.0f) {
+            const double rate = std::log(s_prev / s_last) / std::max(1, i_last - i_prev);
+            const double left = s_last > (double)p.tol ? std::log(s_last / (double)p.tol) / rate : 0.0;
+            batch = (int)std::max(1.0, std::min((double)max_batch, std::floor(left * 0.9)));
+        }
+    }
+    if (n_windowed_out) *n_windowed_out = nwin;
+    return NNC_OK;
 }

@@ -659,9 +659,30 @@ class DeviceKMeans:
                 if st.done:
                     break
                 self._relocate_and_resume(st)
+        if self.group is not None and self.comm is not None:
+            # sharded over the library's own communicator: the same, one call per rank (nnc_kmeans_fit_sharded)
+            st = nat.KMeansStatus()
+            nwin = ctypes.c_int32(0)
+            windowed = self.sorted_everywhere and self.reloc == "auto"
+            if windowed and self.n_min >= 512:
+                # (windows of up to 256 samples; a larger event comes back to _relocate_windowed, which grows the block for good)
+                need = int(self.L.nnc_kmeans_reloc_scratch_bytes_sharded(self.k, 256, self.comm.world))
+                if self._reloc_scratch is None or self._reloc_scratch.numel() < need:
+                    self._reloc_scratch = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            while True:
+                scratch = self._reloc_scratch
+                nat.check(self.L.nnc_kmeans_fit_sharded(self.comm.handle, self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p),
+                                                        self.n_min, self.batch, 1 if windowed else 0,
+                                                        ops._ptr(scratch), 0 if scratch is None else scratch.numel(), self._status_pin.data_ptr(),
+                                                        ctypes.byref(_ticket_counter()), ctypes.byref(st), ctypes.byref(nwin), self.stream))
+                self.n_relocations += nwin.value
+                self.n_reloc_windowed += nwin.value
+                if st.done:
+                    break
+                self._relocate_and_resume(st)
         batch = MAX_ITER if self.one_launch else 1  # the first iteration is where duplicate initial centres surface as empty clusters
         hist = []  # (iteration, sum of squared centre shifts) at the host's look-ins
-        while self.group is not None:
+        while self.group is not None and self.comm is None:
             st = self.iterate_and_look(batch)
             if st.done:
                 break

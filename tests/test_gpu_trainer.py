@@ -170,6 +170,20 @@ def test_sharded_code_path_with_one_rank_group(trainer_mod):
                 assert np.array_equal(a.model.labels_, b.model.labels_)
                 assert torch.equal(a.values, b.values)
                 assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
+            # the whole loop inside the library (nnc_kmeans_fit_sharded) through fits that pause for empty clusters: duplicate forgy
+            # draws on a pruned vector -- windowed relocations with their collectives, the look-ins and the batch sizing
+            events = 0
+            for seed, bits in [(1, 5), (2, 5), (3, 8), (4, 8), (5, 6)]:
+                np.random.seed(seed)
+                a = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=1, bits=bits, mode="forgy")
+                np.random.seed(seed)
+                b = pipeline.compress_layer(torch.from_numpy(w.copy()).cuda(), q=1, bits=bits, mode="forgy", group=group, comm=comm)
+                assert (a.model.n_iter_, a.model.n_relocations_, a.model.stop_reason_) == (b.model.n_iter_, b.model.n_relocations_, b.model.stop_reason_), (seed, bits)
+                assert np.array_equal(a.model.cluster_centers_.view(np.uint32), b.model.cluster_centers_.view(np.uint32))
+                assert np.array_equal(a.model.labels_, b.model.labels_) and torch.equal(a.values, b.values)
+                assert np.array_equal(a.counts, b.counts) and a.total_bits == b.total_bits
+                events += b.model.n_relocations_
+            assert events > 0
         finally:
             comm.close()
     finally:
