@@ -68,6 +68,8 @@ def parse():
                                                                 "the one-call form (nnc_compress_layer_f32): for comparison")
     ap.add_argument("--two-launch", action="store_true", help="Lloyd iterations launch by launch (k_bounds + k_finalize) instead of inside one resident "
                                                               "workgroup (k_lloyd): for comparison")
+    ap.add_argument("--loop", action="store_true", help="Lloyd iterations inside the resident workgroup whatever the number of centres (the library "
+                                                        "picks it by itself up to NNC_KM_LOOP_KMAX centres): for comparison")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse "
                                                       "the multi-rank path with all ranks on one GPU: --one-device)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -166,7 +168,7 @@ def main():
     def step():
         x = w0.clone()  # prune works in place; the copy is device-to-device, inside the timed region
         return pipeline.compress_layer(x, q=args.q, bits=args.bits, mode=args.mode, group=group, comm=comm,
-                                       huffman=True, want_values=True, native=not args.step_by_step, two_launch=args.two_launch)
+                                       huffman=True, want_values=True, native=not args.step_by_step, two_launch=args.two_launch, loop=args.loop)
 
     def barrier():
         if group is not None:

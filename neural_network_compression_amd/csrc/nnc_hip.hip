@@ -327,26 +327,15 @@ __global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks,
         for (int i = threadIdx.x; i < len; i += 1024) buf[i] = chunks[base + i];
         __syncthreads();
         if (threadIdx.x == 0) {
-            // the adds form one dependent chain; the LDS reads must not sit in it: the next 32 values are in flight (registers
-            // nb[]) while the current 32 (cb[]) are folded
             const float4 *b4 = reinterpret_cast<const float4 *>(buf);
             const int nq = len >> 2;
             int qd = 0;
-            if (nq >= 8) {
-                float4 cb[8], nb[8];
+            for (; qd + 8 <= nq; qd += 8) {
+                float4 v[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) cb[u] = b4[u];
-                for (; qd + 16 <= nq; qd += 8) {
+                for (int u = 0; u < 8; u++) v[u] = b4[qd + u];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) nb[u] = b4[qd + 8 + u];
-#pragma unroll
-                    for (int u = 0; u < 8; u++) { acc = acc + cb[u].x; acc = acc + cb[u].y; acc = acc + cb[u].z; acc = acc + cb[u].w; }
-#pragma unroll
-                    for (int u = 0; u < 8; u++) cb[u] = nb[u];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) { acc = acc + cb[u].x; acc = acc + cb[u].y; acc = acc + cb[u].z; acc = acc + cb[u].w; }
-                qd += 8;
+                for (int u = 0; u < 8; u++) { acc = acc + v[u].x; acc = acc + v[u].y; acc = acc + v[u].z; acc = acc + v[u].w; }
             }
             for (; qd < nq; qd++) { const float4 v = b4[qd]; acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w; }
             for (int i = nq << 2; i < len; i++) acc = acc + buf[i];
@@ -904,6 +893,7 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 // integer addition makes the result independent of any ordering.
 //
 #define KM_THREADS 1024
+#define KL_RKEYS 12288 // candidate keys an empty-cluster event inside the one-workgroup loop may have (12 per thread)
 #define KM_NSHARD 8
 #define KM_GMAX 32768
 #define KM_CNT_SAT 31
@@ -964,7 +954,8 @@ struct KmWs {
     // runs only then and clears it; kl_budget = iterations the launches of the current host call may still run
     int32_t wide, kl_budget;
     unsigned long long kl_trace[24]; // diagnostics build: time per phase of k_lloyd (10 ns ticks), summed over the fit
-    int32_t kl_stats[8]; // [0] iterations the loop ran, [1] its launches, [2] of them with centres changing places, [3] iterations handed over, [4] iterations the wide pair ran
+    int32_t kl_stats[8]; // [0] iterations the loop ran, [1] its launches, [2] of them with centres changing places, [3] iterations handed over, [4] iterations the wide pair ran, [5] empty-cluster events the loop settled itself
+    unsigned long long kl_keys[KL_RKEYS]; // candidate keys of such an event (kl_relocate)
     float kl_hL[2 * NNC_KMAX], kl_hR[2 * NNC_KMAX]; // per search (two a boundary: its ranks hint_a / hint_b): the threshold the rank was found for, the local density there (samples per unit)
     KmTab tab[2];
 };
@@ -2180,16 +2171,40 @@ __device__ __forceinline__ KmZone km_pair_zone(const double cp, const double cq,
     if (den > delta) { // (else the two centres are a few ulps apart: the global bound says all there is to say)
         const float cpf = (float)cp, cqf = (float)cq;
         const double Cp = (double)(cpf * cpf), Cq = (double)(cqf * cqf);
-        const double xs = (Cq - Cp) / (2.0 * delta);
+        // (no double division on this path: x* from a float32 reciprocal and one Newton step -- relative error below 3.4e-14, paid
+        // for in w -- and w, which only has to be large enough, from a reciprocal rounded up)
+        const double d2 = 2.0 * delta;
+        double xs;
+        if (d2 > 1e-37 && d2 < 1e37) {
+            const double r0 = (double)__frcp_rn((float)d2);
+            xs = (Cq - Cp) * (r0 * (2.0 - d2 * r0));
+        } else xs = (Cq - Cp) / d2;
         const double Ds = fmax(fabs(Cp - 2.0 * xs * cp), fabs(Cq - 2.0 * xs * cq));
         const double num = U * (2.0 * Ds + 2.0000005 * fabs(xs) * S) * 1.000001 + 1e-42;
-        const double w = (num / den) * 1.000001 + fabs(xs) * 4.5e-16;
+        const double w = (num * km_rcp_up(den)) * 1.000001 + fabs(xs) * 1e-13;
         z.lo = fmax(z.lo, xs - w); z.hi = fmin(z.hi, xs + w);
     }
     return z;
 }
 // how far the crossing point of a pair can lie from its midpoint at most (for the early exit of the loops over the pairs)
 __device__ __forceinline__ double km_pair_slack(const double delta, const double xb) { return 1.25e-7 * xb * xb * km_rcp_up(delta); }
+
+// workgroup barrier that orders LDS traffic only (see km_finalize_body)
+__device__ __forceinline__ void km_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
+// workgroup votes through an LDS word that starts at zero and is used once per launch
+__device__ __forceinline__ int km_vote_or(int *word, const int x)
+{
+    if (__any(x) && (threadIdx.x & 63) == 0) *word = 1;
+    km_lds_barrier();
+    return *word;
+}
+__device__ __forceinline__ int km_vote_count(int *word, const int x) // threads with x != 0
+{
+    const int c = (int)__popcll(__ballot(x != 0));
+    if (c && (threadIdx.x & 63) == 0) atomicAdd(word, c);
+    km_lds_barrier();
+    return *word;
+}
 
 // NT threads: a fit with few centres runs it as a single wave (64) or four (256), for which the many barriers and
 // wave-to-wave hand-overs of the scans cost next to nothing; NT >= k is all it needs (k > 1024 takes two rounds of 1024).
@@ -2200,10 +2215,15 @@ template <int NT, bool ONEWAVE>
 __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out, const bool lazy = false)
 {
     static_assert(!ONEWAVE || NT == 64, "the barrier-free form is for a single wave");
-#define FIN_SYNC() do { if (ONEWAVE) wave_lds_fence(); else __syncthreads(); } while (0)
-#define FIN_OR(x) (ONEWAVE ? (int)__any(x) : __syncthreads_or(x))
-#define FIN_AND(x) (ONEWAVE ? (int)__all(x) : __syncthreads_and(x))
-#define FIN_COUNT(x) (ONEWAVE ? (int)__popcll(__ballot(x)) : __syncthreads_count(x))
+    // The threads of this step talk to each other through LDS only; what they write to global memory is for later kernels.  A
+    // __syncthreads() is a fence over ALL memory (s_waitcnt vmcnt(0): gfx9 counts stores there too), so every barrier behind a
+    // batch of global stores would wait a memory round trip for them -- a microsecond each, and there are a dozen.  km_lds_barrier
+    // orders the LDS traffic only; the stores drain while the step goes on.  The votes go through LDS words (one per site).
+#define FIN_SYNC() do { if (ONEWAVE) wave_lds_fence(); else km_lds_barrier(); } while (0)
+#define FIN_OR(slot, x) (ONEWAVE ? (int)__any(x) : km_vote_or(&fin_votes[slot], (x)))
+#define FIN_AND(slot, x) (ONEWAVE ? (int)__all(x) : !km_vote_or(&fin_votes[slot], !(x)))
+#define FIN_COUNT(slot, x) (ONEWAVE ? (int)__popcll(__ballot(x)) : km_vote_count(&fin_votes[slot], (x)))
+    __shared__ int fin_votes[8];
     __shared__ long long sum_o[NNC_KMAX];
     __shared__ long long cnt_o[NNC_KMAX];
     __shared__ __align__(16) float cnew[NNC_KMAX];
@@ -2222,6 +2242,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
 #define FSTAMP(i) do { if (ftr && tid == 0) ftr[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
     FSTAMP(0);
     if (tid == 0) ws->cells_pending = 0;
+    if (!ONEWAVE && tid < 8) fin_votes[tid] = 0; // (the barrier below is in front of the first vote)
     {   // the tile queue of the pass that produced these sums (k_bounds) is spent
         const int qn = min(ws->q_n, (int)NNC_KMAX);
         for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
@@ -2312,7 +2333,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                 ws->prev_counts[j] = c;
             }
         }
-        const int any_diff = FIN_OR(count_diff);
+        const int any_diff = FIN_OR(0, count_diff);
         if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
     }
     FSTAMP(1);
@@ -2322,7 +2343,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         int my_empty = 0;
         for (int j = tid; j < k; j += NT) my_empty += (cnt_o[j] == 0);
         if (tid == 0) sh_key = 0ull;
-        const int n_empty = FIN_COUNT(my_empty);
+        const int n_empty = FIN_COUNT(1, my_empty);
         if (n_empty > 0 && !resume) {
             int tot_empty = 0;
             if (tid == 0) {
@@ -2405,7 +2426,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             }
         }
         FSTAMP(12);
-        still_sorted = FIN_AND(ok);
+        still_sorted = FIN_AND(2, ok);
         // nearly sorted (two neighbours changed places): a few odd-even transposition passes repair it
         for (int pass = 0; pass < 3 && !still_sorted; pass++) {
             for (int parity = 0; parity < 2; parity++) {
@@ -2421,7 +2442,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                 const float va = cs[p], vb = cs[p + 1];
                 ok2 &= (va < vb) || (va == vb && so[p] < so[p + 1]);
             }
-            still_sorted = FIN_AND(ok2);
+            still_sorted = FIN_AND(3 + pass, ok2);
         }
     }
     FSTAMP(8);
@@ -2508,25 +2529,44 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         int *wave_i = reinterpret_cast<int *>(wave_a);
         int carry_g = -2;
         int wide_zone = 0;
+        // the interval of every pair of NEIGHBOURS once (its upper end bounds the lower centre's zone, its lower end the upper
+        // centre's): the sums of the iteration are spent, their LDS holds the ends
+        // ... and, while there are threads to spare, of the pairs two, three and four apart as well: where centres crowd (relocated
+        // centres side by side in a sparse tail) a centre's zone is the intersection over several of them, and one thread working
+        // through them one after the other holds up the whole step
+        double *zhi = reinterpret_cast<double *>(sum_o), *zlo = reinterpret_cast<double *>(cnt_o);
+        const int zd = ku > 0 ? max(1, min(min(4, NT / max(ku, 1)), NNC_KMAX / max(ku, 1))) : 1; // distances kept in LDS
+        for (int t = tid; t < zd * ku; t += NT) {
+            const int d = t / ku, p = t - d * ku, q = p + d + 1;
+            if (q < ku) {
+                const KmZone z = km_pair_zone((double)cs[p], (double)cs[q], xb); // (distinct values in order: delta > 0)
+                zhi[d * ku + p] = z.hi; zlo[d * ku + q] = z.lo;
+            }
+        }
+        FSTAMP(13);
+        FIN_SYNC();
+        FSTAMP(14);
         for (int rd = 0; rd < rounds; rd++) { // (the raw G_p / H_p go to gcell / hcell; the scans below run over them in place)
             const int p = rd * NT + tid;
             int gp = -2, hp_ = G + 1;
             if (p < ku) {
                 const double cp = (double)cs[p];
-                double right = INFINITY, left = -INFINITY;
-                for (int q = p + 1; q < ku; q++) {
+                double right = p + 1 < ku ? zhi[p] : INFINITY, left = p > 0 ? zlo[p] : -INFINITY;
+                for (int q = p + 2; q < ku; q++) { // pairs further apart matter only where centres crowd
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
                     const double delta = cq - cp;
                     if (mid - km_pair_slack(delta, xb) >= right) break; // every later pair's interval ends further up still
-                    if (delta > 0.0) right = fmin(right, km_pair_zone(cp, cq, xb).hi);
+                    const int d = q - p - 1;
+                    if (delta > 0.0) right = fmin(right, d < zd ? zhi[d * ku + p] : km_pair_zone(cp, cq, xb).hi);
                 }
-                for (int q = p - 1; q >= 0; q--) {
+                for (int q = p - 2; q >= 0; q--) {
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
                     const double delta = cp - cq;
                     if (mid + km_pair_slack(delta, xb) <= left) break;
-                    if (delta > 0.0) left = fmax(left, km_pair_zone(cq, cp, xb).lo);
+                    const int d = p - q - 1;
+                    if (delta > 0.0) left = fmax(left, d < zd ? zlo[d * ku + p] : km_pair_zone(cq, cp, xb).lo);
                 }
                 tab->zl[p] = left; tab->zr[p] = right;
                 ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
@@ -2548,7 +2588,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             }
             if (p < ku) { gcell[p] = gp; hcell[p] = hp_; }
         }
-        if (FIN_OR(wide_zone) && tid == 0) ws->help_hint = 1;
+        FSTAMP(15);
+        if (FIN_OR(6, wide_zone) && tid == 0) ws->help_hint = 1;
         FIN_SYNC();
         FSTAMP(11);
         if (!lazy) { // (the rank-boundary iterations do not use the cell side of the zones: k_cells works it out on demand)
@@ -2802,6 +2843,16 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
                                                       int force = 0, int which = 0, int spec = 0)
 {
     km_cells_body(ws, host_st, host_ticket, ticket, force, which, spec, (int)blockIdx.x);
+}
+
+__device__ __forceinline__ unsigned f32_ordered_bits(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // unsigned order == float order
+}
+__device__ __forceinline__ float f32_from_ordered_bits(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
 
 #include "nnc_lloyd.hpp"
@@ -3074,17 +3125,19 @@ static bool km_lloyd_ok(const nnc_kmeans_params *p, const float *x)
     return (p->flags & NNC_KM_LOOP) || p->k <= NNC_KM_LOOP_KMAX; // (beyond that one compute unit's instruction rate is the bound: include/nnc.h)
 }
 
-static int km_launch_lloyd(const float *xs, KmWs *w, const nnc_kmeans_params *p, int budget_set, void *stream)
+// reloc: the loop settles empty-cluster events itself where it can (kl_relocate) -- for callers that would otherwise enqueue the
+// relocation chain "in case" (nnc_kmeans_fit); a caller that wants to see every pause (nnc_kmeans_iterate) passes 0
+static int km_launch_lloyd(const float *xs, KmWs *w, const nnc_kmeans_params *p, int budget_set, void *stream, int reloc = 0)
 {
     const int kc = (p->k + 7) & ~7;
     const size_t lds = kl_lds_bytes(kc);
     const long long *pb = reinterpret_cast<const long long *>(p->prefix_dev);
     if (p->k <= 128)
         NNC_LAUNCH_PROF(NNC_PROF_LLOYD, (k_lloyd<256>), dim3(1), dim3(256), lds, S(stream), xs, (long long)p->n, w, pb, budget_set, kc,
-                        (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull);
+                        (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull, reloc);
     else
         NNC_LAUNCH_PROF(NNC_PROF_LLOYD, (k_lloyd<KM_THREADS>), dim3(1), dim3(KM_THREADS), lds, S(stream), xs, (long long)p->n, w, pb, budget_set, kc,
-                        (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull);
+                        (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull, reloc);
     LAUNCHCHK("k_lloyd");
     return NNC_OK;
 }
@@ -3092,10 +3145,10 @@ static int km_launch_lloyd(const float *xs, KmWs *w, const nnc_kmeans_params *p,
 // one round: the loop runs until the fit stops, pauses, or an iteration needs the wide pass; k_bounds / k_finalize then run that one
 // iteration (they return at once otherwise).  The look-in, if any, rides on the last launch.
 static int km_launch_lloyd_round(const float *xs, KmWs *w, const nnc_kmeans_params *p, int budget_set, void *stream, void *host_mapped = nullptr,
-                                 uint64_t ticket = 0)
+                                 uint64_t ticket = 0, int reloc = 0)
 {
     int rc;
-    if ((rc = km_launch_lloyd(xs, w, p, budget_set, stream))) return rc;
+    if ((rc = km_launch_lloyd(xs, w, p, budget_set, stream, reloc))) return rc;
     if ((rc = km_launch_accumulate(xs, w, p, stream, 4))) return rc;
     return km_launch_finalize(w, p, FIN_FROM_SHARDS, 0, stream, host_mapped, ticket, true);
 }
@@ -3775,16 +3828,6 @@ __global__ __launch_bounds__(256) void k_topm_hist(const float *__restrict__ d, 
     __syncthreads();
     for (int i = threadIdx.x; i < 4096; i += 256)
         if (h[i]) atomicAdd(&hist[i], (unsigned long long)h[i]);
-}
-
-__device__ __forceinline__ unsigned f32_ordered_bits(float x)
-{
-    const unsigned u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // unsigned order == float order
-}
-__device__ __forceinline__ float f32_from_ordered_bits(unsigned o)
-{
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
 }
 
 __global__ __launch_bounds__(256) void k_topm_compact(const float *__restrict__ d, const float *__restrict__ x, int64_t n,
@@ -4676,7 +4719,7 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
             if ((rc = km_set_lds_attr())) return rc;
             for (int i = 0; i < batch; i++) {
                 const bool last = i == batch - 1;
-                if ((rc = km_launch_lloyd_round(x_iter, w, &p, first_launch ? p.max_iter : -1, stream, (last && !spec) ? sl : nullptr, ticket))) return rc;
+                if ((rc = km_launch_lloyd_round(x_iter, w, &p, first_launch ? p.max_iter : -1, stream, (last && !spec) ? sl : nullptr, ticket, spec ? 1 : 0))) return rc;
                 first_launch = false;
                 if (spec && (rc = km_launch_spec_reloc(x_iter, w, &p, reloc_scratch_dev, stream, last ? sl : nullptr, ticket))) return rc;
             }

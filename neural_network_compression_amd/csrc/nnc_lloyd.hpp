@@ -45,12 +45,18 @@ struct KlHead {
     int wave_i[16];
     double wmax[16], wmin[16];        // per wave: the largest zone end from below, the smallest from above
     KlHeap heap;
+    // relocation of empty clusters inside the loop (kl_relocate)
+    int r_cnt, r_bad, r_pad0, r_pad1;
+    unsigned long long r_keys[8];     // the selected keys, descending (one more than there are empty clusters)
+    unsigned long long r_wkey[2][16]; // per wave: its largest remaining key ...
+    int r_widx[2][16];                // ... and the slot that holds it
+    int r_empty[8], r_old[8];         // the empty clusters (ascending index); the clusters the selected samples leave
 };
 static_assert(sizeof(KlHead) % 16 == 0, "the arrays behind the header are 16-byte aligned");
 
 struct KlArr {
     double *Lb, *Ub;                                                   // per boundary j: L_j, U_j (per centre while the zones are being made: zl, zr)
-    long long *sum_s, *cnt_s, *A, *B, *PA, *PB, *prevc, *hint;          // A/B double as the per-cluster sums / counts in original index order
+    long long *sum_s, *cnt_s, *A, *B, *PA, *PB, *prevc, *hint;          // PA/PB double as the per-cluster sums / counts in original index order
     float *hL, *hR, *cs, *csq, *cnew, *cold, *sq, *call, *Lf, *Uf;         // Lf / Uf: L_j rounded up, U_j rounded down to float32
     uint16_t *so, *perm, *phi, *qj;                                      // phi[j]: the highest centre that can still win below U_j; qj: the labelling chunks' boundaries
 };
@@ -315,17 +321,22 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
     KLSTAMP(9); // distinct + tables
     // zone of every centre: the x-interval on which it can be the float32 arg-min (km_finalize_body's rule and error bound)
     const double xb = fmax(fabs((double)p_lo), fabs((double)p_hi));
+    for (int p = tid; p + 1 < ku; p += NT) { // the interval of every pair of neighbours once: both centres' zones end there
+        const KmZone z = km_pair_zone((double)L.cs[p], (double)L.cs[p + 1], xb);
+        L.Ub[p] = z.hi; L.Lb[p + 1] = z.lo;
+    }
+    __syncthreads();
     for (int p = tid; p < ku; p += NT) {
         const double cp = (double)L.cs[p];
-        double right = INFINITY, left = -INFINITY;
-        for (int q = p + 1; q < ku; q++) {
+        double right = p + 1 < ku ? L.Ub[p] : INFINITY, left = p > 0 ? L.Lb[p] : -INFINITY;
+        for (int q = p + 2; q < ku; q++) {
             const double cq = (double)L.cs[q];
             const double mid = 0.5 * (cp + cq);
             const double delta = cq - cp;
             if (mid - km_pair_slack(delta, xb) >= right) break; // every later pair's interval ends further up still
             if (delta > 0.0) right = fmin(right, km_pair_zone(cp, cq, xb).hi);
         }
-        for (int q = p - 1; q >= 0; q--) {
+        for (int q = p - 2; q >= 0; q--) {
             const double cq = (double)L.cs[q];
             const double mid = 0.5 * (cp + cq);
             const double delta = cp - cq;
@@ -651,15 +662,241 @@ __device__ __forceinline__ void kl_label(const float *__restrict__ xs, const flo
     }
 }
 
-// ---- the M-step and everything behind it: 0 = go on, 1 = stopped (done), 2 = paused for empty clusters --------------------------
+// ---- empty clusters, settled without leaving the loop ------------------------------------------------------------------------------
+// scikit-learn's _relocate_empty_clusters_dense (_k_means_common.pyx:167-211) for the iteration whose sums lie in sumo / cnto (original
+// index order, in LDS): the i-th empty cluster (ascending index) takes the sample with the i-th largest key
+// (float32 squared distance to its own centre, then value -- the keys of k_reloc_select), which leaves the cluster it was labelled
+// with.  On the value-sorted vector the loop knows every sample's label from the ranks of this iteration: [b_{p-1}, a_p) is centre
+// p's, the stretches in between were labelled sample by sample.  Inside a certain stretch the distance to the centre is monotone
+// either side of it, so the candidates are the KL_RW samples at each end of every certain stretch and every sample of the undecided
+// stretches; the selection (one more key than there are empty clusters, so that a tie at the cut shows) is right if the innermost
+// candidate of every end lies STRICTLY below the cut -- the proof k_reloc_select runs on its windows, with the loop's exact ranks in
+// place of windows that must be wide enough.  Returns 1 when the event is settled (sums, counts and ws->partials edited as
+// km_relocate_apply edits them, status counters updated: the caller goes on with the averages), 0 when it is not (more than
+// KL_RM_MAX empty clusters, too many candidates, no proof, every sample on its centre, a cluster that would be left empty): nothing
+// has changed then and the caller pauses as before -- the relocation chain behind the launch, or the host, takes the event.
+#define KL_RW 8      // candidates per end of a certain stretch: the lanes of a group
+#define KL_RM_MAX 7  // empty clusters one event may have here (KL_RM_MAX + 1 keys are selected)
+#define KL_RKPT 12   // candidate keys one thread holds during the selection
 template <int NT>
-__device__ __forceinline__ int kl_finish(KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total, const int k,
-                                         const int kc, int &cur, int &iter, const int Sft, const int max_iter, const float tol_v, const float p_lo,
-                                         const float p_hi, KlDiag *dg)
+__device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L,
+                                           long long *sumo, long long *cnto, const int k, const int nch, const float mean, const int Sft)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = tid >> 3, gl = tid & 7;
+    const int ku = hd->ku, m = hd->n_empty;
+    if (tid == 0 && m > ws->kl_stats[7]) ws->kl_stats[7] = m; // (diagnostics: the largest event seen, why events were passed on)
+    if (m < 1 || m > KL_RM_MAX || 2 * ku > NT) { if (tid == 0) ws->kl_stats[6] |= 1; return 0; }
+    unsigned long long *keys = ws->kl_keys;
+    const int base = 2 * KL_RW * ku;
+    if (tid == 0) { hd->r_cnt = 0; hd->r_bad = 0; }
+    __syncthreads();
+    // ---- the ends of the certain stretches: group q = (centre p, lower / upper end), one sample a lane, the outermost first
+    unsigned inner = 0u; // the largest distance of an innermost candidate that has samples behind it
+    for (int q = g; q < 2 * ku; q += NT / 8) {
+        const int p = q >> 1, side = q & 1;
+        const long long lo_r = p > 0 ? L.B[p - 1] : 0, hi_r = p == ku - 1 ? n : L.A[p];
+        long long r = -1;
+        if (side == 0) { r = lo_r + gl; if (r >= hi_r) r = -1; }
+        else { r = hi_r - 1 - gl; if (r < lo_r + KL_RW) r = -1; } // (a short stretch: its first KL_RW samples are the lower end's)
+        unsigned long long key = 0ull;
+        if (r >= 0) {
+            const float xv = xs[r];
+            const float dd = (xv - mean) - L.cs[p];
+            const float dv = dd * dd;
+            key = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
+            if (gl == KL_RW - 1 && hi_r - lo_r > 2 * KL_RW) inner = max(inner, __float_as_uint(dv));
+        }
+        keys[q * KL_RW + gl] = key;
+    }
+    // ---- the undecided stretches, chunk by chunk as kl_label went through them: exact label, then the distance to that centre
+    const int *qfirst = reinterpret_cast<const int *>(L.call);
+    for (int c = g; c < nch; c += NT / 8) {
+        const int j = (int)L.qj[c];
+        const long long bm = j > 0 ? L.B[j - 1] : 0, a = L.A[j], e = L.B[j];
+        const long long s = a > bm ? a : bm;
+        const int phi = L.phi[j];
+        const int cs_ = phi == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
+        const long long start = s + (long long)cs_ * (c - qfirst[j]);
+        const long long end = start + cs_ < e ? start + cs_ : e;
+        for (long long r = start + gl; r < end; r += 8) {
+            const float xv = xs[r];
+            const float xc = xv - mean;
+            float bestd = L.csq[j] + (-2.0f * (xc * L.cs[j]));
+            int best = j, besto = (int)L.so[j];
+            for (int cc = j + 1; cc <= phi; cc++) {
+                const float d = L.csq[cc] + (-2.0f * (xc * L.cs[cc]));
+                const int oc = (int)L.so[cc];
+                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = cc; besto = oc; }
+            }
+            const float dd = xc - L.cs[best];
+            const float dv = dd * dd;
+            const int slot = base + atomicAdd(&hd->r_cnt, 1);
+            if (slot < KL_RKEYS) keys[slot] = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
+        }
+    }
+    __syncthreads();
+    const int N = base + hd->r_cnt;
+    if (N > KL_RKPT * NT || N > KL_RKEYS) { if (tid == 0) ws->kl_stats[6] |= 2; return 0; }
+    // ---- the m + 1 largest keys: every thread holds its share in registers, one round of workgroup maximum per key
+    unsigned long long kr[KL_RKPT];
+#pragma unroll
+    for (int i = 0; i < KL_RKPT; i++) { const int slot = tid + i * NT; kr[i] = slot < N ? keys[slot] : 0ull; }
+#pragma unroll
+    for (int r = 0; r <= KL_RM_MAX; r++) {
+        if (r <= m) { // (the same on every thread)
+            unsigned long long bk = 0ull;
+            int bi = -1;
+#pragma unroll
+            for (int i = 0; i < KL_RKPT; i++) if (kr[i] > bk) { bk = kr[i]; bi = tid + i * NT; }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) { // equal keys are interchangeable samples: the lower slot goes first
+                const unsigned long long ok = (unsigned long long)__shfl_xor((long long)bk, off);
+                const int oi = __shfl_xor(bi, off);
+                if (ok > bk || (ok == bk && (unsigned)oi < (unsigned)bi)) { bk = ok; bi = oi; }
+            }
+            if (lane == 0) { hd->r_wkey[r & 1][wv] = bk; hd->r_widx[r & 1][wv] = bi; }
+            __syncthreads();
+            bk = 0ull; bi = -1;
+#pragma unroll
+            for (int w = 0; w < NT / 64; w++) {
+                const unsigned long long ok = hd->r_wkey[r & 1][w];
+                const int oi = hd->r_widx[r & 1][w];
+                if (ok > bk || (ok == bk && (unsigned)oi < (unsigned)bi)) { bk = ok; bi = oi; }
+            }
+            if (tid == 0) hd->r_keys[r] = bk;
+            if (bi >= 0 && (bi % NT) == tid) {
+                const int mine = bi / NT;
+#pragma unroll
+                for (int i = 0; i < KL_RKPT; i++) if (i == mine) kr[i] = 0ull;
+            }
+        } else if (tid == 0) hd->r_keys[r] = 0ull;
+    }
+    __syncthreads();
+    // ---- is the selection right, and is there anything to move?
+    const unsigned long long kcut = hd->r_keys[m - 1], ktop = hd->r_keys[0];
+    int bad = 0;
+    if (kcut == 0ull || (ktop >> 32) == 0ull) bad = 1;     // fewer candidates than empty clusters; every sample on its centre
+    if (inner >= (unsigned)(kcut >> 32)) bad = 1;          // samples behind an innermost candidate might reach the cut
+    if (__syncthreads_or(bad)) { if (tid == 0) ws->kl_stats[6] |= (kcut == 0ull ? 4 : 0) | ((ktop >> 32) == 0ull ? 8 : 0) | 16; return 0; }
+    // ---- the empty clusters in ascending order; the cluster each selected sample leaves (the float32 arg-min over ALL centres,
+    // first minimum -- km_relocate_apply)
+    {
+        const int rounds = (k + NT - 1) / NT;
+        int carry = 0;
+        for (int rd = 0; rd < rounds; rd++) {
+            const int j = rd * NT + tid;
+            const int e = (j < k && cnto[j] == 0) ? 1 : 0;
+            const unsigned long long bal = __ballot(e);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) hd->wave_i[wv] = __popcll(bal);
+            __syncthreads();
+            int pre = carry, tot = carry;
+            for (int w = 0; w < NT / 64; w++) { const int c = hd->wave_i[w]; if (w < wv) pre += c; tot += c; }
+            if (e && pre + before < 8) hd->r_empty[pre + before] = j;
+            carry = tot;
+            __syncthreads();
+        }
+    }
+    for (int i = wv; i < m; i += NT / 64) { // wave-uniform
+        const float xv = f32_from_ordered_bits((unsigned)(hd->r_keys[i] & 0xFFFFFFFFull));
+        const float xc = xv - mean;
+        float best = INFINITY;
+        int old = 0x7fffffff;
+        for (int j = lane; j < k; j += 64) {
+            const float cv = L.cold[j];
+            const float dj = cv * cv + (-2.0f * (xc * cv));
+            if (dj < best) { best = dj; old = j; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off);
+            const int oo = __shfl_xor(old, off);
+            if (ob < best || (ob == best && oo < old)) { best = ob; old = oo; }
+        }
+        if (old == 0x7fffffff) old = 0;
+        if (lane == 0) hd->r_old[i] = old;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nb = 0;
+        for (int i = 0; i < m; i++) { // no cluster may be left without a sample (scikit-learn does not look again; neither path here tries)
+            int leave = 0;
+            for (int q = 0; q < m; q++) leave += hd->r_old[q] == hd->r_old[i];
+            if (cnto[hd->r_old[i]] - leave < 1) nb = 1;
+        }
+        hd->r_bad = nb;
+        if (nb) ws->kl_stats[6] |= 32;
+        if (!nb) {
+            for (int i = 0; i < m; i++) {
+                const float xv = f32_from_ordered_bits((unsigned)(hd->r_keys[i] & 0xFFFFFFFFull));
+                const long long v = (long long)fix_f32(xv - mean, Sft);
+                const int old = hd->r_old[i], nw = hd->r_empty[i];
+                sumo[old] -= v; cnto[old] -= 1;
+                sumo[nw] += v; cnto[nw] += 1;
+            }
+            for (int i = 0; i < m; i++) { // (ws->partials: what the relocation kernels edit; partials_local stays as labelled, as there)
+                const int old = hd->r_old[i], nw = hd->r_empty[i];
+                ws->partials[old] = sumo[old]; ws->partials[k + old] = cnto[old];
+                ws->partials[nw] = sumo[nw]; ws->partials[k + nw] = cnto[nw];
+            }
+            // what scikit-learn leaves to numpy.argpartition (km_relocate_apply): the pairing of several, a tie at the cut
+            if (m > 1) ws->st.reloc_multi += 1;
+            const unsigned long long kn = hd->r_keys[m];
+            if (kn != 0ull && (kn >> 32) == (kcut >> 32) && kn != kcut) ws->st.reloc_ties += 1;
+            ws->st.n_relocated += 1; // (the host does not see this event: it counts them from here)
+            ws->reloc_fail = 0;
+            ws->kl_stats[5] += 1;
+        }
+    }
+    __syncthreads();
+    return hd->r_bad ? 0 : 1;
+}
+
+// ---- the M-step and everything behind it: 0 = go on, 1 = stopped (done), 2 = paused for empty clusters --------------------------
+// second half (from sums and counts in original index order, no cluster empty): _average_centers, _center_shift, the tolerance
+// test, the tables of the new centres
+template <int NT>
+__device__ __forceinline__ int kl_finish_tail(KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long *sumo, const long long *cnto, const int k,
+                                              int &cur, int &iter, const int Sft, const int max_iter, const float tol_v, const float p_lo,
+                                              const float p_hi, KlDiag *dg)
+{
+    const int tid = threadIdx.x;
+    for (int j = tid; j < k; j += NT) {
+        const float c = (float)ldexp((double)sumo[j] / (double)cnto[j], -Sft);
+        L.cnew[j] = c;
+        const float d = c - L.cold[j];
+        const float s2 = d * d;
+        const float sft = (float)sqrt((double)s2);
+        L.sq[j] = sft * sft;
+    }
+    __syncthreads();
+    kl_pairwise<NT>(hd, L.sq, k);
+    const float tot = hd->tot;
+    iter += 1;
+    int done = 0;
+    if (tot <= tol_v) done = 1;
+    else if (iter >= max_iter) done = 2;
+    cur ^= 1;
+    if (tid == 0) {
+        ws->st.iter = iter; ws->st.shift_tot = tot; ws->st.done = done;
+        ws->st.paused = 0; ws->st.n_empty = 0;
+        ws->cur = cur;
+    }
+    for (int j = tid; j < k; j += NT) { const float c = L.cnew[j]; ws->c[cur][j] = c; L.cold[j] = c; }
+    __syncthreads();
+    KLSTAMP(7); // shift, pairwise sum, state
+    kl_tables<NT>(ws, hd, L, k, cur, false, p_lo, p_hi, dg);
+    return done ? 1 : 0;
+}
+
+template <int NT>
+__device__ __forceinline__ int kl_finish(const float *__restrict__ xs, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total,
+                                         const int k, const int kc, int &cur, int &iter, const float mean, const int Sft, const int max_iter,
+                                         const float tol_v, const float p_lo, const float p_hi, const int nch, const int reloc, KlDiag *dg)
 {
     const int tid = threadIdx.x;
     const int ku = hd->ku;
-    long long *sumo = L.A, *cnto = L.B; // original index order (the boundary results are spent once they are in registers)
+    long long *sumo = L.PA, *cnto = L.PB; // original index order (the prefix sums are spent once they are in registers; the ranks A / B stay for kl_relocate)
     // ---- certain stretches: [b_{p-1}, a_p) is centre p's; its sum is a difference of prefix sums
     long long rs[2], rc[2];
     int ro[2];
@@ -702,46 +939,23 @@ __device__ __forceinline__ int kl_finish(KmWs *__restrict__ ws, KlHead *hd, cons
         __syncthreads();
         if (my_empty) atomicAdd(&hd->n_empty, my_empty);
         __syncthreads();
-        if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = hd->n_empty; ws->tab[cur].n_ovf = 0; }
-        return 2;
+        // (with every count unchanged the host's strict-convergence check is due first: km_spec_decide)
+        if (!(reloc && !(iter >= 1 && !any_diff) && kl_relocate<NT>(xs, n, ws, hd, L, sumo, cnto, k, nch, mean, Sft))) {
+            if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = hd->n_empty; ws->tab[cur].n_ovf = 0; }
+            return 2;
+        }
     }
-    // ---- _average_centers, _center_shift, the tolerance test
-    for (int j = tid; j < k; j += NT) {
-        const float c = (float)ldexp((double)sumo[j] / (double)cnto[j], -Sft);
-        L.cnew[j] = c;
-        const float d = c - L.cold[j];
-        const float s2 = d * d;
-        const float sft = (float)sqrt((double)s2);
-        L.sq[j] = sft * sft;
-    }
-    __syncthreads();
-    kl_pairwise<NT>(hd, L.sq, k);
-    const float tot = hd->tot;
-    iter += 1;
-    int done = 0;
-    if (tot <= tol_v) done = 1;
-    else if (iter >= max_iter) done = 2;
-    cur ^= 1;
-    if (tid == 0) {
-        ws->st.iter = iter; ws->st.shift_tot = tot; ws->st.done = done;
-        ws->st.paused = 0; ws->st.n_empty = 0;
-        ws->cur = cur;
-    }
-    for (int j = tid; j < k; j += NT) { const float c = L.cnew[j]; ws->c[cur][j] = c; L.cold[j] = c; }
-    __syncthreads();
-    KLSTAMP(7); // shift, pairwise sum, state
-    kl_tables<NT>(ws, hd, L, k, cur, false, p_lo, p_hi, dg);
-    return done ? 1 : 0;
+    return kl_finish_tail<NT>(ws, hd, L, sumo, cnto, k, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi, dg);
 }
 
 // ---- the same step when nothing unusual happens: every centre distinct (one thread per cluster, k <= NT), no empty cluster, the
 // order of the centres unchanged.  Then nothing has to change places: thread p owns the p-th centre in value order from the sums
-// to the zones, and the step needs six workgroup barriers instead of some forty.  Returns -1 (before it has changed anything
+// to the zones, and the step needs seven workgroup barriers instead of some forty.  Returns -1 (before it has changed anything
 // that the general step would not change in the same way) when that does not hold; else 0 = go on, 1 = stopped, 2 = paused.
 template <int NT>
-__device__ __forceinline__ int kl_finish_fast(KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total, const int k,
-                                              int &cur, int &iter, const int Sft, const int max_iter, const float tol_v, const float p_lo,
-                                              const float p_hi, KlDiag *dg)
+__device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total,
+                                              const int k, int &cur, int &iter, const float mean, const int Sft, const int max_iter, const float tol_v,
+                                              const float p_lo, const float p_hi, const int nch, const int reloc, KlDiag *dg)
 {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int p = tid;
@@ -778,13 +992,21 @@ __device__ __forceinline__ int kl_finish_fast(KmWs *__restrict__ ws, KlHead *hd,
     KLSTAMP(5);
     const int any_empty = hd->f_empty, any_diff = hd->f_diff;
     if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
-    if (any_empty) { // pause: the relocation chain (or the host) takes over; nothing else of the state has changed
+    if (any_empty) {
+        // the relocation here (kl_relocate), then the general second half; or pause: the relocation chain (or the host) takes over,
+        // nothing else of the state has changed
+        long long *sumo = L.PA, *cnto = L.PB; // (spent: their values are in sm / c)
         if (tid == 0) hd->n_empty = 0;
         __syncthreads();
         if (empty) atomicAdd(&hd->n_empty, 1);
+        if (mine) { sumo[o] = sm; cnto[o] = c; } // k distinct centres: every index is some thread's
         __syncthreads();
-        if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = hd->n_empty; ws->tab[cur].n_ovf = 0; hd->f_empty = 0; hd->f_diff = 0; }
-        return 2;
+        if (tid == 0) { hd->f_empty = 0; hd->f_diff = 0; }
+        if (!(reloc && !(iter >= 1 && !any_diff) && kl_relocate<NT>(xs, n, ws, hd, L, sumo, cnto, k, nch, mean, Sft))) {
+            if (tid == 0) { ws->st.paused = 1; ws->st.n_empty = hd->n_empty; ws->tab[cur].n_ovf = 0; }
+            return 2;
+        }
+        return kl_finish_tail<NT>(ws, hd, L, sumo, cnto, k, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi, dg);
     }
     // ---- NumPy's pairwise sum of the squared shifts (leaves now, eight lanes each; the first wave folds them behind the barrier),
     // and: is the order of the centres still the same, all of them distinct?
@@ -851,16 +1073,23 @@ __device__ __forceinline__ int kl_finish_fast(KmWs *__restrict__ ws, KlHead *hd,
     // the wave by shuffles, across the waves through sixteen LDS words
     const double xb = fmax(fabs((double)p_lo), fabs((double)p_hi));
     double left = -INFINITY, right = INFINITY;
+    if (mine && p + 1 < k) { // the interval of every pair of neighbours once: both centres' zones end there
+        const KmZone z = km_pair_zone((double)cn, (double)L.cs[p + 1], xb);
+        L.Ub[p] = z.hi; L.Lb[p + 1] = z.lo;
+    }
+    __syncthreads();
     if (mine) {
         const double cp = (double)cn;
-        for (int q = p + 1; q < k; q++) {
+        if (p + 1 < k) right = L.Ub[p];
+        if (p > 0) left = L.Lb[p];
+        for (int q = p + 2; q < k; q++) {
             const double cq = (double)L.cs[q];
             const double mid = 0.5 * (cp + cq);
             const double delta = cq - cp;
             if (mid - km_pair_slack(delta, xb) >= right) break;
             if (delta > 0.0) right = fmin(right, km_pair_zone(cp, cq, xb).hi);
         }
-        for (int q = p - 1; q >= 0; q--) {
+        for (int q = p - 2; q >= 0; q--) {
             const double cq = (double)L.cs[q];
             const double mid = 0.5 * (cp + cq);
             const double delta = cp - cq;
@@ -915,7 +1144,7 @@ __device__ __forceinline__ int kl_finish_fast(KmWs *__restrict__ ws, KlHead *hd,
 template <int NT>
 __global__ __launch_bounds__(NT) void k_lloyd(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, const long long *__restrict__ pblk,
                                               int budget_set, int kc, nnc_kmeans_status *host_st, unsigned long long *host_ticket,
-                                              unsigned long long ticket)
+                                              unsigned long long ticket, int reloc)
 {
     extern __shared__ __align__(16) unsigned char kl_smem[];
 #ifdef NNC_DIAG
@@ -980,12 +1209,13 @@ __global__ __launch_bounds__(NT) void k_lloyd(const float *__restrict__ xs, long
             if (hd->slow || hd->nch > KL_QMAX) { if (tid == 0) { ws->wide = 1; ws->help_hint = 1; hd->slow = 1; } break; } // (a long stretch: every wave of the wide pass had better look at the tile queue)
             kl_label<NT>(xs, mean, Sft, hd, L);
             KLSTAMP(14); // this wave's labelling
+            const int nch = hd->nch; // (the chunk list stays as it is until the next kl_chunks: kl_relocate goes through it again)
             __syncthreads();
             if (tid == 0) hd->nch = 0;
             KLSTAMP(15); // ... until the last group is through
             int r = -1;
-            if (hd->ku == k && k <= NT) r = kl_finish_fast<NT>(ws, hd, L, n, total, k, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi, dg);
-            else r = kl_finish<NT>(ws, hd, L, n, total, k, kc, cur, iter, Sft, max_iter, tol_v, p_lo, p_hi, dg);
+            if (hd->ku == k && k <= NT) r = kl_finish_fast<NT>(xs, ws, hd, L, n, total, k, cur, iter, mean, Sft, max_iter, tol_v, p_lo, p_hi, nch, reloc, dg);
+            else r = kl_finish<NT>(xs, ws, hd, L, n, total, k, kc, cur, iter, mean, Sft, max_iter, tol_v, p_lo, p_hi, nch, reloc, dg);
             budget--; ran++;
             if (r) break;
         }
@@ -997,7 +1227,7 @@ __global__ __launch_bounds__(NT) void k_lloyd(const float *__restrict__ xs, long
             if (ran == 0 || !(ws->st.done | ws->st.paused)) {
                 if (hd->slow) ws->kl_stats[3] += 1;                     // handed over: a long undecided stretch / a search that did not settle
 #ifdef NNC_DIAG
-                if (hd->slow) { ws->kl_stats[5] = hd->pad0; ws->kl_stats[6] = hd->pad1; ws->kl_stats[7] = hd->pad2; }
+                (void)0;
 #endif
             }
         }

@@ -400,7 +400,8 @@ class DeviceKMeans:
         multi-workgroup pass.  Synchronises."""
         out = (ctypes.c_int32 * 8)()
         nat.check(self.L.nnc_kmeans_loop_stats(self.ws.data_ptr(), out, self.stream))
-        return {"loop_iterations": out[0], "loop_launches": out[1], "reordered": out[2], "handed_over": out[3], "wide_iterations": out[4]}
+        return {"loop_iterations": out[0], "loop_launches": out[1], "reordered": out[2], "handed_over": out[3], "wide_iterations": out[4],
+                "relocated_in_loop": out[5], "passed_on_why": out[6], "largest_event": out[7]}
 
     def iterate_and_look(self, iters: int) -> nat.KMeansStatus:
         """`iters` iterations and the state behind them.  On one GPU the look-in rides on the batch's last launch."""

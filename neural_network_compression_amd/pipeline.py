@@ -142,7 +142,7 @@ def _layer_host_block():
     return blk
 
 
-def _compress_layer_native(x: torch.Tensor, q, std_smooth: bool, bits: int, mode: str, want_values: bool, two_launch: bool = False):
+def _compress_layer_native(x: torch.Tensor, q, std_smooth: bool, bits: int, mode: str, want_values: bool, two_launch: bool = False, loop: bool = False):
     """nnc_compress_layer_f32 (include/nnc.h) on a whole tensor of one GPU, modes linear / density.  Returns a LayerResult, or
     (mask, sigma, threshold, nzeroed) of the pruned tensor when the library leaves the fit to the step-by-step path."""
     import ctypes
@@ -161,7 +161,7 @@ def _compress_layer_native(x: torch.Tensor, q, std_smooth: bool, bits: int, mode
     pinned, ticket, res = _layer_host_block()
     lp = nat.LayerParams(q=float(np.float32(q)) if q is not None else 0.0, prune=1 if q is not None else 0, std_smooth=1 if std_smooth else 0,
                          bits=int(bits), mode=1 if mode == "density" else 0, want_values=1 if want_values else 0,
-                         km_flags=nat.NNC_KM_TWO_LAUNCH if two_launch else 0)
+                         km_flags=nat.NNC_KM_TWO_LAUNCH if two_launch else (nat.NNC_KM_LOOP if loop else 0))
     nat.check(L.nnc_compress_layer_f32(x.data_ptr(), n, ctypes.byref(lp), ops._ptr(mask), labels.data_ptr(), ops._ptr(values), ws.data_ptr(), ws_bytes,
                                        pinned.data_ptr(), pinned.numel(), ctypes.byref(ticket), ctypes.byref(res), ops._stream(x)))
     mask_b = mask   # (uint8, like ops.prune_)
@@ -187,12 +187,13 @@ def _compress_layer_native(x: torch.Tensor, q, std_smooth: bool, bits: int, mode
 def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int = 4, mode: str = "linear",
                    with_cdf: bool | None = None, group=None, huffman: bool = True,
                    want_values: bool = True, comm=None, arith: str = "auto", native: bool = True,
-                   two_launch: bool = False) -> LayerResult:
+                   two_launch: bool = False, loop: bool = False) -> LayerResult:
     """One layer tensor (or this rank's shard of it), in place on `x` for the pruning part.
     ``group``: torch.distributed group of one rank per GPU when `x` is a shard; ``comm`` (sharding.RcclComm over the same
     ranks) moves the per-iteration exchange of the fit into the C library.  ``arith``: kmeans.fit_vector.  ``native``: let
     the library run the whole layer as one call where it can (same results; ``False``: the step-by-step path).
-    ``two_launch``: iterate launch by launch instead of inside one resident workgroup (include/nnc.h, NNC_KM_TWO_LAUNCH; same results)."""
+    ``two_launch``: iterate launch by launch instead of inside one resident workgroup (include/nnc.h, NNC_KM_TWO_LAUNCH; same results);
+    ``loop``: the resident workgroup whatever the number of centres (NNC_KM_LOOP; the library's own choice otherwise)."""
     x = x.reshape(-1)
     ops._require_cuda(x, "x", torch.float32)
     n_total = n_min = x.numel()
@@ -210,7 +211,7 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
             and 1 <= bits <= 10 and n_total >= (2 ** bits) + 1 and x.is_contiguous()):
         # the whole layer as one call into the library (nnc_compress_layer_f32); it hands the fit back when that needs the
         # step-by-step path (short tensor with the density init, full-pass relocation, strict-convergence check)
-        out = _compress_layer_native(x, q, std_smooth, bits, mode, want_values, two_launch)
+        out = _compress_layer_native(x, q, std_smooth, bits, mode, want_values, two_launch, loop)
         if isinstance(out, LayerResult):
             return out
         pre = out          # (mask, sigma, threshold, nzeroed): the tensor is pruned already
@@ -247,7 +248,7 @@ def compress_layer(x: torch.Tensor, q=None, std_smooth: bool = True, bits: int =
         model, values = _kmeans.fit_reference(x, space, want_values=want_values)
     else:
         km = _kmeans.DeviceKMeans(x, space, group=group, stats=lstats, x_sorted=x_sorted, n_total=n_total, n_min=n_min, comm=comm,
-                                  two_launch=two_launch)
+                                  two_launch=two_launch, loop=loop)
         model, values = km.fit(want_values=want_values)
     k = int(model.cluster_centers_.size)
     counts = lengths = lhist = total = None

@@ -164,3 +164,29 @@ def test_the_iterations_really_run_inside_the_loop(km):
     assert not d.lloyd   # one compute unit's instruction rate is the bound there: launch per iteration
     d.fit()
     assert d.loop_stats()["loop_iterations"] == 0
+
+
+def test_empty_clusters_are_settled_inside_the_loop(km):
+    """Fits that pause for empty clusters (duplicate forgy draws / duplicate density centres on a pruned vector): under fit() the
+    loop relocates the far samples itself (kl_relocate: candidates from the exact ranks of the iteration, proof that nothing behind
+    them reaches the cut), falls back to the relocation chain where it cannot -- and the trajectory is the launch-per-iteration one,
+    event for event."""
+    in_loop = events = 0
+    for n, k, seed in [(235_200, 32, 1), (235_200, 32, 2), (627_200, 33, 4), (500_000, 257, 6), (120_000, 64, 7), (300_000, 129, 8), (90_000, 24, 9)]:
+        x = _pruned(n, 900 + seed)
+        init = _init(x, k, "forgy", seed)
+        t = torch.from_numpy(x).cuda()
+        a_km = km.DeviceKMeans(t, init, loop=True)
+        a, av = a_km.fit()
+        b, bv = km.DeviceKMeans(t, init, two_launch=True).fit()
+        assert (a.n_iter_, a.n_relocations_, a.stop_reason_) == (b.n_iter_, b.n_relocations_, b.stop_reason_), (n, k, seed)
+        assert (a.reloc_tie_, a.n_reloc_multi_) == (b.reloc_tie_, b.n_reloc_multi_), (n, k, seed)
+        assert np.array_equal(a.cluster_centers_.view(np.uint32), b.cluster_centers_.view(np.uint32))
+        assert np.array_equal(a.labels_, b.labels_) and torch.equal(av, bv)
+        ob = orc.kmeans_lloyd(x, init, accum="B")
+        assert a.n_iter_ == ob.n_iter_ and np.array_equal(a.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
+        st = a_km.loop_stats()
+        in_loop += st["relocated_in_loop"]
+        events += a.n_relocations_
+        assert st["relocated_in_loop"] <= a.n_relocations_
+    assert events > 0 and in_loop > 0, (events, in_loop)

@@ -29,10 +29,15 @@ def pair_zone(cp, cq, xb):
     if den > delta:
         Cp = np.float64(np.float32(cp) * np.float32(cp))
         Cq = np.float64(np.float32(cq) * np.float32(cq))
-        xs = (Cq - Cp) / (2.0 * delta)
+        d2 = 2.0 * delta
+        if 1e-37 < d2 < 1e37:   # float32 reciprocal + one Newton step (the device avoids the double division)
+            r0 = np.float64(np.float32(1.0) / np.float32(d2))
+            xs = (Cq - Cp) * (r0 * (2.0 - d2 * r0))
+        else:
+            xs = (Cq - Cp) / d2
         Ds = max(abs(Cp - 2.0 * xs * cp), abs(Cq - 2.0 * xs * cq))
         num = U * (2.0 * Ds + 2.0000005 * abs(xs) * S) * 1.000001 + 1e-42
-        w = (num / den) * 1.000001 + abs(xs) * 4.5e-16
+        w = (num * rcp_up(den)) * 1.000001 + abs(xs) * 1e-13
         lo, hi = max(lo, xs - w), min(hi, xs + w)
     return lo, hi
 

@@ -14,8 +14,8 @@ pipeline.prune_sharded_(x, 1.0, True, None)
 from neural_network_compression_amd.common import utility as U
 cdfs = U.get_weight_distribution(x, skip_zeros=True)
 space = np.asarray(U._init_space(x, x.numel(), 8, "density", cdfs), dtype=np.float32)
-for tl in (False, True):
-    d = km.DeviceKMeans(x, space, two_launch=tl)
+for tl in (False, False, True, True):
+    d = km.DeviceKMeans(x, space, two_launch=tl, loop=not tl)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m, _ = d.fit()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0

@@ -13,7 +13,7 @@ st = kmeans.LayerStats(x)
 xs = kmeans.sorted_copy(x, st)
 cdfs = pipeline.weight_distribution_sorted(xs, st)
 space = pipeline.initial_centroids(x, 8, "density", cdfs)
-km = kmeans.DeviceKMeans(x, space, stats=st, x_sorted=xs)
+km = kmeans.DeviceKMeans(x, space, stats=st, x_sorted=xs, two_launch=True)
 target = [int(a) for a in sys.argv[1:]] or [2, 30]
 trace = torch.zeros(8192, dtype=torch.int64, pin_memory=True)
 it = 0
