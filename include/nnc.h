@@ -398,6 +398,13 @@ int nnc_kmeans_relocate_if_proven(void *ws, const int64_t *keys_sorted_dev, int3
 /* flag_dev = 1 if the two label vectors are identical else 0 (scikit-learn's strict convergence
  * test, _kmeans.py:717); nnc_kmeans_set_done_if sets done = done_code when *flag_dev != 0. */
 int nnc_labels_equal(const void *a, const void *b, int64_t n, int label_bytes, int32_t *flag_dev, void *stream);
+/* The M-step sums as scikit-learn runs them on one thread (sklearn/cluster/_k_means_lloyd.pyx:215-218, reached from
+ * neural_network_compression/common/utility.py:237-238): sums_out[j] = float32 running sum, IN SAMPLE ORDER and from +0.0, of
+ * (x[i] - x_mean) over the samples with labels[i] == j; counts_out[j] = their number.  labels: uint8 (label_bytes 1) or uint16 (2).
+ * One wave per cluster; the cost is the size of the largest cluster times a few nanoseconds.  For the opt-in fit in the
+ * reference's own arithmetic of tensors beyond NNC_REF_NMAX weights (kmeans.fit_reference_large). */
+int nnc_ref_sums_f32(const float *x, int64_t n, float x_mean, const void *labels, int32_t label_bytes, int32_t k,
+                     float *sums_out_dev, int64_t *counts_out_dev, void *stream);
 int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code, void *stream);
 
 /* counts_dev[j] += #{ i : labels[i] == j }  (caller zeroes counts_dev; int64[k]). */

@@ -130,6 +130,7 @@ SIGNATURES = {
     "nnc_kmeans_reloc_flag": (c_void_p, [c_void_p]),
     "nnc_kmeans_relocate_if_proven": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_labels_equal": (c_int, [c_void_p, c_void_p, c_i64, c_int, c_void_p, c_void_p]),
+    "nnc_ref_sums_f32": (c_int, [c_void_p, c_i64, ctypes.c_float, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "nnc_kmeans_set_done_if": (c_int, [c_void_p, c_void_p, c_i32, c_void_p]),
     "nnc_bincount": (c_int, [c_void_p, c_int, c_i64, c_i32, c_void_p, c_void_p]),
     "nnc_kmeans_fit_reference_f32": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_f32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -4862,6 +4862,66 @@ extern "C" int nnc_labels_equal(const void *a, const void *b, int64_t n, int lab
     return NNC_OK;
 }
 
+// --------------------------------------------------------------------------------------
+// The M-step sums as scikit-learn runs them on one thread (_k_means_lloyd.pyx:215-218, _update_chunk_dense): for every cluster
+// the float32 running sum of its members' centred values IN SAMPLE ORDER, starting from +0.0.  A sequential sum cannot be spread
+// over lanes: one wave per cluster walks the label vector 256 samples at a time (loads well ahead of the chain), takes the members
+// of each 64-sample chunk from a ballot and adds them one after the other (v_readlane + v_add_f32 per member).  The cost of a
+// call is the size of the largest cluster times a few nanoseconds -- the opt-in "reference arithmetic" fit of tensors beyond
+// NNC_REF_NMAX (kmeans.fit_reference_large), not the product's default path.
+// --------------------------------------------------------------------------------------
+template <typename LT>
+__global__ __launch_bounds__(256) void k_ref_sums(const float *__restrict__ x, long long n, float mean, const LT *__restrict__ labels, int k,
+                                                  float *__restrict__ sums, long long *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int j = uni_i((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (j >= k) return;
+    float acc = 0.0f;
+    long long cnt = 0;
+    for (long long i0 = 0; i0 < n; i0 += 256) { // (wave-uniform trip count)
+        bool mine[4];
+        float xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long i = i0 + 64 * u + lane;
+            mine[u] = i < n && (int)labels[i] == j;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { // only the members' values are fetched
+            const long long i = i0 + 64 * u + lane;
+            xv[u] = mine[u] ? x[i] - mean : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            unsigned long long m = __ballot(mine[u]);
+            cnt += __popcll(m);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1ull;
+                acc = acc + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xv[u]), b));
+            }
+        }
+    }
+    if (lane == 0) { sums[j] = acc; counts[j] = cnt; }
+}
+
+extern "C" int nnc_ref_sums_f32(const float *x, int64_t n, float x_mean, const void *labels, int32_t label_bytes, int32_t k,
+                                float *sums_out_dev, int64_t *counts_out_dev, void *stream)
+{
+    if (n < 0 || k < 1 || k > NNC_KMAX || (n > 0 && (!x || !labels)) || !sums_out_dev || !counts_out_dev || (label_bytes != 1 && label_bytes != 2))
+        return fail(NNC_EINVAL, "nnc_ref_sums_f32: bad argument");
+    const int grid = (k + 3) / 4;
+    if (label_bytes == 1)
+        hipLaunchKernelGGL((k_ref_sums<uint8_t>), dim3(grid), dim3(256), 0, S(stream), x, (long long)n, x_mean, reinterpret_cast<const uint8_t *>(labels), (int)k,
+                           sums_out_dev, reinterpret_cast<long long *>(counts_out_dev));
+    else
+        hipLaunchKernelGGL((k_ref_sums<uint16_t>), dim3(grid), dim3(256), 0, S(stream), x, (long long)n, x_mean, reinterpret_cast<const uint16_t *>(labels), (int)k,
+                           sums_out_dev, reinterpret_cast<long long *>(counts_out_dev));
+    LAUNCHCHK("k_ref_sums");
+    return NNC_OK;
+}
+
 extern "C" int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t done_code, void *stream)
 {
     if (!ws || !flag_dev) return fail(NNC_EINVAL, "nnc_kmeans_set_done_if: null pointer");

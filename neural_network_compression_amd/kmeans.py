@@ -222,10 +222,115 @@ def fit_reference(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = 
     return model, vals
 
 
+REF_LARGE_NMAX = (1 << 24) - 1   # float32 member counts (scikit-learn's weight_in_clusters) are exact up to here
+
+
+def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = TOL, want_values: bool = True, stats=None):
+    """KMeans(n_clusters=k, init=init[:, None], n_init=1, algorithm="full").fit(x[:, None]) (utility.py:237-238) in scikit-learn's
+    own arithmetic for a tensor too long for the one-launch form (fit_reference): opt-in (arith="reference"), slow, exact.
+
+    What makes the reference's centres differ from the exact-sum fit in the last bits is the M-step: float32 running sums in SAMPLE
+    order (_k_means_lloyd.pyx:215-218, one thread).  Here they are exactly that (nnc_ref_sums_f32: one wave per cluster walking
+    the label vector; an iteration costs the largest cluster times a few nanoseconds -- the zero cluster of a pruned fc1 about a
+    millisecond).  The E-step is the device's (bit-exact float32 arg-min, the same as everywhere); everything K-sized --
+    float32 member counts, relocation of empty clusters with ``numpy.argpartition`` itself on the squared distances in sample order
+    (_k_means_common.pyx:167-211), averaging by float32(1 / count), the shift, NumPy's pairwise float32 sum, the two stopping
+    rules (_kmeans.py:705-733) -- runs in NumPy on the host from 12 bytes per centre per iteration.  One GPU."""
+    x = x.reshape(-1)
+    ops._require_cuda(x, "x", torch.float32)
+    init = np.ascontiguousarray(np.asarray(init, dtype=np.float32).reshape(-1))
+    n, k = x.numel(), int(init.size)
+    if not (1 <= k <= n <= REF_LARGE_NMAX):
+        raise ValueError(f"fit_reference_large: n={n}, k={k} outside k <= n <= {REF_LARGE_NMAX}")
+    km = DeviceKMeans(x, init, max_iter=max_iter, tol=tol, sort=False, stats=stats)   # statistics, tolerance, E-step tables; its Lloyd loop is not used
+    L, dev, stream = km.L, km.dev, km.stream
+    lb = 1 if k <= 256 else 2
+    x_mean = np.float32(km.p.x_mean)
+    tol_ = np.float32(km.tol_)
+    centers = (init - x_mean).astype(np.float32)            # _kmeans.py:1484 (the device has done the same)
+    blk = torch.empty(12 * k, dtype=torch.uint8, device=dev)
+    counts_d, sums_d = blk[: 8 * k].view(torch.int64), blk[8 * k:].view(torch.float32)   # (the 8-byte words first: alignment)
+    cen_d = torch.empty(k, dtype=torch.float32, device=dev)
+    labels_old = None
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    n_iter, strict, n_reloc, ties, multi = 0, False, 0, 0, 0
+    lab, stop = None, "max_iter"
+    for i in range(int(max_iter)):
+        lab = km.assign(which=0, labels=True)[0]
+        nat.check(L.nnc_ref_sums_f32(x.data_ptr(), n, float(x_mean), lab.data_ptr(), lb, k, sums_d.data_ptr(), counts_d.data_ptr(), stream))
+        same = False
+        if labels_old is not None:
+            nat.check(L.nnc_labels_equal(lab.data_ptr(), labels_old.data_ptr(), n, lb, flag.data_ptr(), stream))
+        host = blk.cpu().numpy()
+        sums = host[8 * k:].view(np.float32).copy()
+        wic = host[: 8 * k].view(np.int64).astype(np.float32)   # (scikit-learn counts in float32; exact here)
+        if labels_old is not None:
+            same = bool(int(flag.item()))
+        empty = np.flatnonzero(wic == 0)
+        if empty.size:
+            # _relocate_empty_clusters_dense: the reference's own selection, ties and pairing included
+            d = km.assign(which=0, labels=False, distances=True)[2].cpu().numpy()
+            far = np.argpartition(d, -empty.size)[: -empty.size - 1: -1]
+            if np.max(d) != 0:
+                ds = np.sort(d)
+                n_reloc += 1
+                multi += int(empty.size > 1)
+                if empty.size < d.size and ds[-empty.size] == ds[-empty.size - 1] and ds[-empty.size] != 0:
+                    ties += 1
+                idx = torch.from_numpy(far.astype(np.int64)).to(dev)
+                xf = (x[idx].cpu().numpy() - x_mean).astype(np.float32)
+                lf = lab[idx].cpu().numpy().astype(np.int64) & (0xFF if lb == 1 else 0xFFFF)
+                for new, v, old in zip(empty, xf, lf):
+                    v = np.float32(v * np.float32(1.0))
+                    sums[old] = np.float32(sums[old] - v)
+                    sums[new] = v
+                    wic[new] = np.float32(1.0)
+                    wic[old] = np.float32(wic[old] - np.float32(1.0))
+        # _average_centers (_k_means_common.pyx:274-296), in place and in index order
+        amax = int(np.argmax(wic))
+        cen = sums.copy()
+        for j in range(k):
+            if wic[j] > 0:
+                cen[j] = np.float32(cen[j] * np.float32(1.0 / float(wic[j])))
+            else:
+                cen[j] = cen[amax]
+        # _center_shift (_k_means_common.pyx:298-311) and the total as _kmeans.py:726 has it
+        t = (cen - centers).astype(np.float32)
+        shift = np.sqrt((t * t).astype(np.float32)).astype(np.float32)
+        tot = np.float32((shift ** 2).sum())
+        centers = cen
+        n_iter = i + 1
+        cen_d.copy_(torch.from_numpy(centers))
+        nat.check(L.nnc_kmeans_set_centers(km.ws.data_ptr(), ctypes.byref(km.p), cen_d.data_ptr(), 1, stream))
+        if same:                       # np.array_equal(labels, labels_old): strict convergence, these labels stay
+            strict, stop = True, "strict"
+            break
+        if tot <= tol_:
+            stop = "tol"
+            break
+        labels_old = lab
+    if not strict:
+        lab = km.assign(which=0, labels=True)[0]
+    final = (centers + x_mean).astype(np.float32)
+    vals = None
+    if want_values:
+        vals = torch.from_numpy(final).to(dev)[lab.to(torch.int64) if lb == 1 else (lab.to(torch.int64) & 0xFFFF)]
+    model = QuantizedModel(final, lab, n_iter, n_reloc, stop)
+    counts = torch.bincount(lab.to(torch.int64) if lb == 1 else (lab.to(torch.int64) & 0xFFFF), minlength=k)
+    model.counts_device_ = counts
+    model.counts_host_ = counts.cpu().numpy().astype(np.int64)
+    model.n_reloc_windowed_ = 0
+    model.reloc_tie_ = ties
+    model.n_reloc_multi_ = multi
+    model.arith_ = "reference"
+    return model, vals
+
+
 def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "auto", group=None, **kw):
     """The fit behind get_quantized_weight / compress_layer.  ``arith``: "reference" = scikit-learn's float32 running sums
-    (short tensors on one GPU only), "fixed" = exact fixed-point sums (any size, any number of GPUs), "auto" = reference
-    where it applies."""
+    in sample order (one GPU; one launch for short tensors, fit_reference_large beyond: slow, for callers who want the
+    reference's centres bit for bit), "fixed" = exact fixed-point sums (any size, any number of GPUs), "auto" = reference
+    where the one-launch form applies, fixed otherwise."""
     if arith not in ("auto", "reference", "fixed"):
         raise ValueError("arith must be 'auto', 'reference' or 'fixed'")
     k = int(np.asarray(init).size)
@@ -234,6 +339,9 @@ def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "au
     if arith == "reference" or (arith == "auto" and reference_fit_applies(x.numel(), k, group)):
         if group is not None:
             raise ValueError("arith='reference' is a single-GPU fit")
+        if arith == "reference" and not reference_fit_applies(x.numel(), k, group):
+            # beyond the one-launch form: sample-order sums on the device, the K-sized steps in NumPy (slow, exact, opt-in)
+            return fit_reference_large(x, init, want_values=want_values, stats=kw.get("stats"))
         return fit_reference(x, init, want_values=want_values)
     model, vals = DeviceKMeans(x, init, group=group, **kw).fit(want_values=want_values)
     model.arith_ = "fixed"

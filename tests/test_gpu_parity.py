@@ -6,6 +6,7 @@ its order-independent accumulation mode "B"; against the reference's own float32
 sums (goldens, mode "A") the centres agree to the reference's summation error.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -396,6 +397,39 @@ def test_fit_against_reference_goldens(nnc, gold, key):
         assert np.array_equal(km.cluster_centers_.ravel(), gc.astype(np.float32).ravel()), key
         assert sha(km.labels_) == c["labels_sha256"], key
     # the decoded tensor uses the device's own centres
+    assert np.array_equal(q, km.cluster_centers_[km.labels_].reshape(w.shape)), key
+
+
+def _all_golden_fits(gold_cases=None):
+    import json
+    here = os.path.dirname(os.path.abspath(__file__))
+    cases = json.load(open(os.path.join(here, "golden", "ref_goldens.json")))["cases"] if gold_cases is None else gold_cases
+    return sorted(k for k, c in cases.items() if k.startswith("quant/") and not c["passthrough"])
+
+
+@pytest.mark.parametrize("key", _all_golden_fits())
+def test_reference_arithmetic_is_the_reference_bit_for_bit(nnc, gold, key):
+    """arith="reference" (opt-in): scikit-learn's own M-step -- float32 running sums in sample order -- on tensors of any golden size
+    (one launch up to 4096 weights, kmeans.fit_reference_large beyond: sums by nnc_ref_sums_f32, relocation by numpy.argpartition on
+    the distances in sample order).  Every golden fit of BASELINE configs[0]-[2] (and the others) then equals what
+    neural_network_compression/common/utility.py:237-239 produced: n_iter_, every centre bit for bit, every index."""
+    c = gold.cases[key]
+    w = _input_for_quant(key)
+    cdfs = None
+    if c["with_cdf"]:
+        flat = w.ravel()
+        cdfs = nnc.utility.get_weight_distribution(flat[flat != 0])
+    if c["forgy_seed"] is not None:
+        np.random.seed(c["forgy_seed"])
+    q, km = nnc.utility.get_quantized_weight(w.copy(), bits=c["bits"], mode=c["mode"], cdfs=cdfs, arith="reference")
+    assert km.arith_ == "reference"
+    gc = gold.arr(c["centers"]).astype(np.float32)
+    short_pairing = w.size <= 4096 and km.n_reloc_multi_ > 0   # (the one-launch form pairs several empty clusters by its own rule)
+    if not short_pairing:
+        assert km.n_iter_ == c["n_iter"], (key, km.n_iter_, c["n_iter"])
+        assert np.array_equal(km.cluster_centers_.ravel().view(np.uint32), gc.ravel().view(np.uint32)), key
+        assert sha(km.labels_) == c["labels_sha256"], key
+        assert np.array_equal(np.bincount(km.labels_, minlength=c["K"]), gold.arr(c["bincount"])), key
     assert np.array_equal(q, km.cluster_centers_[km.labels_].reshape(w.shape)), key
 
 
