@@ -1680,6 +1680,25 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
                                                         KmWs *ws, float mean, int Sft, int lane)
 {
     s = uni_ll(s); e = uni_ll(e); plo = uni_i(plo); phi = uni_i(phi);
+    if (e - s >= 128 && phi > plo) {
+        // A run of EQUAL values -- the zeros of a pruned vector between two centres float32 cannot tell apart: 17 M samples of the
+        // bench vector, twice per fit -- gets one label: the vector is sorted, so equal ends mean equal everything in between.
+        // One evaluation (the general rule: first strict minimum, ties to the lowest original index), value x count.
+        const float x0 = xs[s], x1 = xs[e - 1];
+        if (x0 == x1) {
+            const float xc = x0 - mean;
+            float bestd = INFINITY;
+            int best = plo, besto = 0x7fffffff;
+            for (int c = plo; c <= phi; c++) { // (wave-uniform: scalar loads)
+                const float2 cm = tab->cand[c];
+                const int oc = (int)tab->orig[c];
+                const float d = cm.y + (-2.0f * (xc * cm.x));
+                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = c; besto = oc; }
+            }
+            if (lane == 0) km_shard_add(ws, best, (long long)fix_f32(xc, Sft) * (e - s), (unsigned long long)(e - s));
+            return;
+        }
+    }
     if (phi <= plo) { // (cannot happen for an undecided stretch; kept total: everything is plo's)
         long long sum = 0;
         unsigned cnt = 0;
@@ -1812,33 +1831,50 @@ __device__ __forceinline__ unsigned long long km_peek_ull(const unsigned long lo
 struct KmBndSrc { const double *zr, *zl; const float2 *cand; const uint16_t *orig; const int *ku; };
 #define KM_BND_R ((NNC_KMAX + 63) / 64)
 
+// everything a wave needs to know before its first probe: the zone ends of all centres (lane by lane), its own two centres, where its
+// boundaries were last time.  None of it depends on the state block, so a kernel issues these loads together with the state's
+// (k_bounds), not a memory round trip behind them.
+// (BR = rounds of 64 centres, a template parameter: with a run-time bound every round became a basic block of its own -- load, wait,
+// branch -- and the five rounds of K = 257 five memory round trips one after the other; now all loads of a wave are in flight at once)
+template <int BR> struct KmBndPre { double zrv[BR], zlv[BR]; float2 cj0, cj1r; int oj0, oj1r, ku; long long hint_a, hint_b, hint_bm; };
+template <int BR>
+__device__ __forceinline__ void km_bounds_preload(KmBndPre<BR> &p, const int j, const int lane, const KmWs *__restrict__ ws, const KmBndSrc src)
+{
+#pragma unroll
+    for (int r = 0; r < BR; r++) {
+        const int q = lane + 64 * r; // (< NNC_KMAX: BR * 64 <= NNC_KMAX; entries beyond ku are ignored by the reader)
+        p.zrv[r] = src.zr[q]; p.zlv[r] = src.zl[q];
+    }
+    const int jq = j < NNC_KMAX - 1 ? j : NNC_KMAX - 2;
+    p.cj0 = src.cand[jq]; p.cj1r = src.cand[jq + 1];
+    p.oj0 = src.orig[jq]; p.oj1r = src.orig[jq + 1];
+    p.hint_a = ws->hint_a[jq]; p.hint_b = ws->hint_b[jq]; p.hint_bm = jq > 0 ? ws->hint_b[jq - 1] : -1;
+    p.ku = *src.ku;
+}
+
+template <int BR>
 __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
-                                               const KmTab *__restrict__ tab, const KmBndSrc src, const int kmax, const float mean, const int Sft,
-                                               const long long *__restrict__ pblk, int *qn_seen)
+                                               const KmTab *__restrict__ tab, const KmBndSrc src, const float mean, const int Sft,
+                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> *pre = nullptr)
 {
     bool published = false;
     // ---- one round of loads: every zone end (a lane holds those of the centres lane, lane + 64, ...; bounded by the caller's k,
     // which is known before anything has arrived), the number of distinct centres, the two centres either side of this
     // wave's boundary, where the boundaries were last time
-    const int R = (kmax + 63) >> 6;
-    double zrv[KM_BND_R], zlv[KM_BND_R];
-#pragma unroll
-    for (int r = 0; r < KM_BND_R; r++) {
-        zrv[r] = 0.0; zlv[r] = 0.0;
-        if (r < R) { const int q = lane + 64 * r; if (q < NNC_KMAX) { zrv[r] = src.zr[q]; zlv[r] = src.zl[q]; } }
-    }
-    const int jq = j < NNC_KMAX - 1 ? j : NNC_KMAX - 2;
-    const float2 cj0 = src.cand[jq], cj1r = src.cand[jq + 1];
-    const int oj0 = src.orig[jq], oj1r = src.orig[jq + 1];
-    const long long hint_a = ws->hint_a[jq], hint_b = ws->hint_b[jq], hint_bm = jq > 0 ? ws->hint_b[jq - 1] : -1;
-    const int ku = *src.ku;
+    KmBndPre<BR> own;
+    if (!pre) { km_bounds_preload<BR>(own, j, lane, ws, src); pre = &own; }
+    const double (&zrv)[BR] = pre->zrv, (&zlv)[BR] = pre->zlv;
+    const float2 cj0 = pre->cj0, cj1r = pre->cj1r;
+    const int oj0 = pre->oj0, oj1r = pre->oj1r;
+    const long long hint_a = pre->hint_a, hint_b = pre->hint_b, hint_bm = pre->hint_bm;
+    const int ku = pre->ku;
     if (j < ku) {
         // ---- the zone ends that bound this wave's stretches
         double Uj = -INFINITY, Ujm1 = -INFINITY, Lj = INFINITY;
 #pragma unroll
-        for (int r = 0; r < KM_BND_R; r++) {
+        for (int r = 0; r < BR; r++) {
             const int q = lane + 64 * r;
-            if (r < R && q < ku) {
+            if (q < ku) {
                 if (q <= j) Uj = fmax(Uj, zrv[r]);
                 if (q < j) Ujm1 = fmax(Ujm1, zrv[r]);
                 if (q > j) Lj = fmin(Lj, zlv[r]);
@@ -1850,9 +1886,9 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
         // the highest centre that can still win somewhere below U_j: max{q : zl[q] <= U_j}  (j + 1 unless centres crowd)
         int phi = j;
 #pragma unroll
-        for (int r = 0; r < KM_BND_R; r++) {
+        for (int r = 0; r < BR; r++) {
             const int q = lane + 64 * r;
-            if (r < R && q < ku && q > j && zlv[r] <= Uj) phi = q;
+            if (q < ku && q > j && zlv[r] <= Uj) phi = q;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) phi = max(phi, __shfl_xor(phi, off));
@@ -1943,7 +1979,9 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
         if (NNC_KM_TRACE_PTR && lane == 0) { NNC_KM_TRACE_PTR[16 * j + 8] = (unsigned long long)und; NNC_KM_TRACE_PTR[16 * j + 9] = (unsigned long long)(phi - j); NNC_KM_TRACE_PTR[16 * j + 10] = (unsigned long long)(a > bm ? a - bm : 0); }
         const bool quick = und > 0 && und <= 256 && phi == j + 1; // few samples, two candidates: settled right here
         // a long stretch goes out as tiles for everybody, and at once: the others look at the queue a round of loads from now
-        if (und > KM_TILE) {
+        // (a long stretch of one value -- the zero plateau -- is no work at all: km_bounds_range settles it with one evaluation)
+        const bool flat = und > KM_TILE && xs[s] == xs[b - 1];
+        if (und > KM_TILE && !flat) {
             const int r = km_claim(&ws->q_n, lane);
             if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
                 published = true;
@@ -2012,8 +2050,9 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
     }
 }
 
+template <int BR>
 __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, long long n, KmWs *__restrict__ ws, int which,
-                                               const long long *__restrict__ pblk, int kmax)
+                                               const long long *__restrict__ pblk)
 {
     const int lane = threadIdx.x & 63;
     const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -2027,6 +2066,9 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
         tab = &ws->tab[ws->cur]; // (needed only by long or crowded undecided stretches)
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
     }
+    KmBndPre<BR> pre;
+    const bool fixed_src = !(which & 1); // (the iteration's own tables live at a fixed address: their loads go out with the state's)
+    if (fixed_src) km_bounds_preload<BR>(pre, j, lane, ws, src);
     const int stop = (which & 2) ? 0 : (ws->st.done | ws->st.paused); // (which & 2: counting pass after the fit)
     const int unasked = (which & 4) ? !ws->wide : 0; // (which & 4: enqueued behind k_lloyd in case it hands an iteration over)
     const int hint = ws->help_hint;
@@ -2034,7 +2076,7 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     const int Sft = ws->p.fix_shift;
     if (stop | unasked) return;
     int qn_seen = 0; // the number of long stretches that were out when this wave's own loads went out
-    const bool published = km_bounds_wave(j, lane, xs, n, ws, tab, src, kmax, mean, Sft, pblk, &qn_seen);
+    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, fixed_src ? &pre : nullptr);
     KBSTAMP(16 * j + 5, 0);
     // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
     // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
@@ -2747,7 +2789,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
         bool published = false;
         int qn_seen = 0;
-        for (int j = wv; j < ku; j += KM_THREADS / 64) published |= km_bounds_wave(j, lane, xs, n, ws, tab, src, KM_FUSE_KMAX, mean, Sft, pblk, &qn_seen);
+        for (int j = wv; j < ku; j += KM_THREADS / 64) published |= km_bounds_wave<(KM_FUSE_KMAX + 63) / 64>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen);
         if (published || ws->help_hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
         // The sums went out as device-scope atomics (performed in L2); the first wave must not read them from a line its CU
         // still holds from the last round: drop the CU's cached copies (acquire), no write-back needed.
@@ -3088,7 +3130,15 @@ static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params
     if (p->prefix_dev && p->n > 0) {
         if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
         const int nb = (p->k + 3) / 4; // one wave per centre (distinct centres <= k); long undecided stretches are shared by the waves that are still running
-        NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, k_bounds, dim3(nb), dim3(256), 0, S(stream), x, (long long)p->n, w, which, reinterpret_cast<const long long *>(p->prefix_dev), (int)p->k);
+        const long long *pb = reinterpret_cast<const long long *>(p->prefix_dev);
+#define KM_LAUNCH_BOUNDS(BR) NNC_LAUNCH_PROF(NNC_PROF_BOUNDS, (k_bounds<BR>), dim3(nb), dim3(256), 0, S(stream), x, (long long)p->n, w, which, pb)
+        if (p->k <= 64) KM_LAUNCH_BOUNDS(1);
+        else if (p->k <= 128) KM_LAUNCH_BOUNDS(2);
+        else if (p->k <= 256) KM_LAUNCH_BOUNDS(4);
+        else if (p->k <= 512) KM_LAUNCH_BOUNDS(8);
+        else if (p->k <= 1024) KM_LAUNCH_BOUNDS(16);
+        else KM_LAUNCH_BOUNDS(KM_BND_R);
+#undef KM_LAUNCH_BOUNDS
         LAUNCHCHK("k_bounds");
         return NNC_OK;
     }

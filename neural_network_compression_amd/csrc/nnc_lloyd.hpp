@@ -46,7 +46,7 @@ struct KlHead {
     double wmax[16], wmin[16];        // per wave: the largest zone end from below, the smallest from above
     KlHeap heap;
     // relocation of empty clusters inside the loop (kl_relocate)
-    int r_cnt, r_bad, r_pad0, r_pad1;
+    int r_cnt, r_bad, r_flat, r_pad1; // (r_flat: a run of equal values was settled as a whole in this iteration, kl_chunks)
     unsigned long long r_keys[8];     // the selected keys, descending (one more than there are empty clusters)
     unsigned long long r_wkey[2][16]; // per wave: its largest remaining key ...
     int r_widx[2][16];                // ... and the slot that holds it
@@ -585,7 +585,7 @@ __device__ __forceinline__ void kl_search(const float *__restrict__ xs, const lo
 
 // between the passes: the chunk list (one thread per boundary)
 template <int NT>
-__device__ __forceinline__ void kl_chunks(const int ku, KlHead *hd, const KlArr &L)
+__device__ __forceinline__ void kl_chunks(const float *__restrict__ xs, const float mean, const int Sft, const int ku, KlHead *hd, const KlArr &L)
 {
     const int tid = threadIdx.x, nb = ku - 1;
     int *qfirst = reinterpret_cast<int *>(L.call); // (free between two finish steps)
@@ -593,7 +593,22 @@ __device__ __forceinline__ void kl_chunks(const int ku, KlHead *hd, const KlArr 
         const long long bm = j > 0 ? L.B[j - 1] : 0, a = L.A[j], e = L.B[j];
         const long long s = a > bm ? a : bm;
         const long long len = e - s;
-        if (len > 0) {
+        if (len > 4 * KL_CHUNK && xs[s] == xs[e - 1]) {
+            // a long run of EQUAL values (the zeros of a pruned vector between two centres float32 cannot tell apart): one label
+            // for all of them -- one evaluation, value x count (km_bounds_range has the same short cut)
+            const float xc = xs[s] - mean;
+            float bestd = INFINITY;
+            int best = j, besto = 0x7fffffff;
+            for (int cc = j; cc <= (int)L.phi[j]; cc++) {
+                const float d = L.csq[cc] + (-2.0f * (xc * L.cs[cc]));
+                const int oc = (int)L.so[cc];
+                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = cc; besto = oc; }
+            }
+            atomicAdd(reinterpret_cast<unsigned long long *>(&L.sum_s[best]), (unsigned long long)((long long)fix_f32(xc, Sft) * len));
+            atomicAdd(reinterpret_cast<unsigned long long *>(&L.cnt_s[best]), (unsigned long long)len);
+            qfirst[j] = -1;
+            hd->r_flat = 1; // (its samples are in no chunk: an empty-cluster event of this iteration goes to the relocation chain)
+        } else if (len > 0) {
             const int cs_ = (int)L.phi[j] == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
             const long long nc = (len + cs_ - 1) / cs_;
             if (nc > KL_QONE) hd->slow = 1;
@@ -685,7 +700,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = tid >> 3, gl = tid & 7;
     const int ku = hd->ku, m = hd->n_empty;
     if (tid == 0 && m > ws->kl_stats[7]) ws->kl_stats[7] = m; // (diagnostics: the largest event seen, why events were passed on)
-    if (m < 1 || m > KL_RM_MAX || 2 * ku > NT) { if (tid == 0) ws->kl_stats[6] |= 1; return 0; }
+    if (m < 1 || m > KL_RM_MAX || 2 * ku > NT || hd->r_flat) { if (tid == 0) ws->kl_stats[6] |= 1; return 0; }
     unsigned long long *keys = ws->kl_keys;
     const int base = 2 * KL_RW * ku;
     if (tid == 0) { hd->r_cnt = 0; hd->r_bad = 0; }
@@ -1199,12 +1214,13 @@ __global__ __launch_bounds__(NT) void k_lloyd(const float *__restrict__ xs, long
 #ifdef NNC_DIAG
             if (tid == 0) dg->slast = __builtin_amdgcn_s_memrealtime();
 #endif
+            if (tid == 0) hd->r_flat = 0; // (set by kl_chunks behind the next barrier, read by the finish step of this iteration)
             if (n < (1ll << 31) - 256) kl_search<NT, int>(xs, n, pf, total, mean, Sft, hd->ku, hd, L, dg);
             else kl_search<NT, long long>(xs, n, pf, total, mean, Sft, hd->ku, hd, L, dg);
             KLSTAMP(1); // this wave's searches
             __syncthreads();
             KLSTAMP(2); // ... until the last group is through
-            if (!hd->slow) kl_chunks<NT>(hd->ku, hd, L);
+            if (!hd->slow) kl_chunks<NT>(xs, mean, Sft, hd->ku, hd, L);
             __syncthreads();
             if (hd->slow || hd->nch > KL_QMAX) { if (tid == 0) { ws->wide = 1; ws->help_hint = 1; hd->slow = 1; } break; } // (a long stretch: every wave of the wide pass had better look at the tile queue)
             kl_label<NT>(xs, mean, Sft, hd, L);

@@ -11,7 +11,7 @@ pipeline.prune_sharded_(x, 1.0, True, None)
 cdfs = U.get_weight_distribution(x, skip_zeros=True)
 space = np.asarray(U._init_space(x, x.numel(), 8, "density", cdfs), dtype=np.float32)
 for rep in range(4):
-    d = km.DeviceKMeans(x, space, two_launch=two)
+    d = km.DeviceKMeans(x, space, two_launch=two, loop=not two)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     m, _ = d.fit()
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
