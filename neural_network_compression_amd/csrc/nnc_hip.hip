@@ -1565,6 +1565,11 @@ __device__ float wave_pairwise_sum(F elem, int n, PwHeap *hp)
 #define KM_PB NNC_PREFIX_BLOCK
 #define KM_PG 1024 // blocks per group of the two-level prefix
 #define KM_TILE 2048
+#define KM_ACC_W 256 // candidates of a crowded stretch whose sums a wave gathers in LDS
+// samples per tile of a long undecided stretch: the work of a tile is samples x candidates, so a stretch many centres compete for
+// (a crowd of relocated centres side by side: 66 candidates for 11 000 samples in the bench fit's second iteration, 120 us in six
+// tiles of 2048) is cut finer -- KM_TILE for two candidates, 64 samples for sixty-four and more
+__host__ __device__ __forceinline__ int km_tile_len(int ncand) { int t = (2 * KM_TILE / (ncand < 2 ? 2 : ncand)) & ~63; return t < 64 ? 64 : t; }
 #define KM_Q_VALID (1ull << 62)
 
 // a value every lane holds alike, moved to scalar registers (so that the control flow that depends on it is scalar)
@@ -1740,18 +1745,22 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
     // cannot tell two centres apart the winner changes from one sample to the next, so the sums are gathered per candidate in
     // LDS (one slot per candidate and wave) and go to the global sums once per call: thousands of samples of one stretch
     // would otherwise queue up on the same few addresses.
-    __shared__ unsigned long long acc_sum[KM_THREADS / 64][64];
-    __shared__ unsigned acc_cnt[KM_THREADS / 64][64];
+    // (KM_ACC_W slots a wave: beyond that -- never seen -- the sums go out as runs of equal labels, two global atomics a run, which
+    // for a crowd is two atomics a sample on a handful of addresses: the 66 candidates of the bench fit's second iteration took
+    // 100 us that way when the slots were 64)
+    __shared__ unsigned long long acc_sum[KM_THREADS / 64][KM_ACC_W];
+    __shared__ unsigned acc_cnt[KM_THREADS / 64][KM_ACC_W];
     const int wv = (int)(threadIdx.x >> 6);
     const int ncand = phi - plo + 1;
-    const bool use_lds = ncand <= 64;
-    if (use_lds) { acc_sum[wv][lane] = 0ull; acc_cnt[wv][lane] = 0u; }
+    const bool use_lds = ncand <= KM_ACC_W;
+    if (use_lds) for (int c = lane; c < ncand; c += 64) { acc_sum[wv][c] = 0ull; acc_cnt[wv][c] = 0u; }
     int run_p = -1;
     unsigned run_n = 0;
     long long run_s = 0;
     float2 cm0 = make_float2(0.0f, 0.0f);
     int om0 = 0x7fffffff;
-    if (use_lds && lane < ncand) { cm0 = tab->cand[plo + lane]; om0 = (int)tab->orig[plo + lane]; }
+    const bool one_group = ncand <= 64; // the candidates stay in the lanes' registers over the whole call
+    if (one_group && lane < ncand) { cm0 = tab->cand[plo + lane]; om0 = (int)tab->orig[plo + lane]; }
     wave_lds_fence();
     for (long long i0 = s; i0 < e; i0 += 256) {
         float xc[4], bestd[4];
@@ -1767,7 +1776,7 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
         for (int g0 = plo; g0 <= phi; g0 += 64) {
             float2 cm = cm0;
             int om = om0;
-            if (!use_lds) {
+            if (!one_group) {
                 const int mine = g0 + lane;
                 cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
                 om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
@@ -1800,7 +1809,7 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
     }
     if (use_lds) {
         wave_lds_fence();
-        if (lane < ncand) km_shard_add(ws, plo + lane, (long long)acc_sum[wv][lane], (unsigned long long)acc_cnt[wv][lane]);
+        for (int c = lane; c < ncand; c += 64) if (acc_cnt[wv][c]) km_shard_add(ws, plo + c, (long long)acc_sum[wv][c], (unsigned long long)acc_cnt[wv][c]);
     } else if (run_n) km_shard_add(ws, run_p, run_s, run_n);
 }
 
@@ -1980,8 +1989,9 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
         const bool quick = und > 0 && und <= 256 && phi == j + 1; // few samples, two candidates: settled right here
         // a long stretch goes out as tiles for everybody, and at once: the others look at the queue a round of loads from now
         // (a long stretch of one value -- the zero plateau -- is no work at all: km_bounds_range settles it with one evaluation)
-        const bool flat = und > KM_TILE && xs[s] == xs[b - 1];
-        if (und > KM_TILE && !flat) {
+        const int tile = km_tile_len(phi - j + 1);
+        const bool flat = und > tile && xs[s] == xs[b - 1];
+        if (und > tile && !flat) {
             const int r = km_claim(&ws->q_n, lane);
             if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
                 published = true;
@@ -2032,20 +2042,42 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
                                                const KmTab *__restrict__ tab, const float mean, const int Sft)
 {
     // (relaxed on purpose: an acquire per look would drop the caches of a thousand waves)
+    // Sixty-four records a look: lane r reads record r, so a walk through the queue is one round trip to the memory side, not one
+    // per record (with a few dozen records out -- the iterations right after a mass relocation -- every wave of the launch used
+    // to spend its hundred microseconds walking, whatever there was left to do).
     const int nrec = min(km_peek_i(&ws->q_n), (int)NNC_KMAX);
-    for (int r = 0; r < nrec; r++) {
-        const unsigned long long w0 = km_peek_ull(&ws->q_w0[r]), w1 = km_peek_ull(&ws->q_w1[r]);
-        if (!(w0 & KM_Q_VALID) || !(w1 & KM_Q_VALID)) continue; // not out yet: its publisher will see to it
-        const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
-        const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
-        const int ntiles = (int)((e - s + KM_TILE - 1) / KM_TILE);
-        if (km_peek_i(&ws->q_next[r]) >= ntiles) continue; // (spent: no need to bump its counter again)
-        int t = km_claim(&ws->q_next[r], lane);
-        while (t < ntiles) {
-            const long long ts = s + (long long)t * KM_TILE;
-            const long long te = ts + KM_TILE < e ? ts + KM_TILE : e;
-            km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
-            t = km_claim(&ws->q_next[r], lane);
+    for (int r0 = 0; r0 < nrec; r0 += 64) {
+        const int rl = r0 + lane;
+        unsigned long long w0 = 0ull, w1 = 0ull;
+        int nx = 0x7fffffff;
+        if (rl < nrec) {
+            w0 = __hip_atomic_load(&ws->q_w0[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            w1 = __hip_atomic_load(&ws->q_w1[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nx = __hip_atomic_load(&ws->q_next[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool live = false;
+        if ((w0 & KM_Q_VALID) && (w1 & KM_Q_VALID)) { // (else not out yet: its publisher will see to it)
+            const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
+            const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
+            const int tile = km_tile_len(phi - plo + 1);
+            live = nx < (int)((e - s + tile - 1) / tile); // (spent records: no need to bump their counters again)
+        }
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const unsigned long long v0 = (unsigned long long)__shfl((long long)w0, b), v1 = (unsigned long long)__shfl((long long)w1, b);
+            const long long s = (long long)(v0 & ((1ull << 40) - 1)), e = (long long)(v1 & ((1ull << 40) - 1));
+            const int plo = (int)((v0 >> 40) & 0xFFFFF), phi = (int)((v1 >> 40) & 0xFFFFF);
+            const int tile = km_tile_len(phi - plo + 1);
+            const int ntiles = (int)((e - s + tile - 1) / tile);
+            int t = km_claim(&ws->q_next[r0 + b], lane);
+            while (t < ntiles) {
+                const long long ts = s + (long long)t * tile;
+                const long long te = ts + tile < e ? ts + tile : e;
+                km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
+                t = km_claim(&ws->q_next[r0 + b], lane);
+            }
         }
     }
 }

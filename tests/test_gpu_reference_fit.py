@@ -91,8 +91,15 @@ def test_arguments(km):
         km.fit_reference(x, np.zeros(4, dtype=np.float32))            # longer than NNC_REF_NMAX
     with pytest.raises(ValueError):
         km.fit_reference(x[:100], np.zeros(129, dtype=np.float32))    # more centres than NNC_REF_KMAX (and than samples)
-    with pytest.raises(ValueError):
-        km.fit_vector(x, np.zeros(4, dtype=np.float32), arith="reference")
+    # beyond the one-launch form the same arithmetic runs step by step (fit_reference_large): against the oracle's mode A
+    init = np.linspace(-0.1, 0.1, 4).astype(np.float32)
+    model, vals = km.fit_vector(x, init, arith="reference")
+    assert model.arith_ == "reference"
+    oa = orc.kmeans_lloyd(x.cpu().numpy(), init, accum="A")
+    assert model.n_iter_ == oa.n_iter_
+    assert np.array_equal(model.cluster_centers_.ravel().view(np.uint32), oa.cluster_centers_.ravel().view(np.uint32))
+    assert np.array_equal(model.labels_, oa.labels_)
+    assert np.array_equal(vals.cpu().numpy(), oa.cluster_centers_.ravel()[oa.labels_])
     model, _ = km.fit_vector(x, np.linspace(-0.1, 0.1, 4).astype(np.float32), arith="auto")
     assert model.arith_ == "fixed"
     model, _ = km.fit_vector(x[:4096], np.linspace(-0.1, 0.1, 4).astype(np.float32), arith="auto")
