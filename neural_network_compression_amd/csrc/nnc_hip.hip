@@ -1565,6 +1565,7 @@ __device__ float wave_pairwise_sum(F elem, int n, PwHeap *hp)
 #define KM_PB NNC_PREFIX_BLOCK
 #define KM_PG 1024 // blocks per group of the two-level prefix
 #define KM_TILE 2048
+#define KM_ZONE_REACH 12 // neighbours either side whose pair with a centre is looked at for its zone (km_finalize_body)
 #define KM_ACC_W 256 // candidates of a crowded stretch whose sums a wave gathers in LDS
 // samples per tile of a long undecided stretch: the work of a tile is samples x candidates, so a stretch many centres compete for
 // (a crowd of relocated centres side by side: 66 candidates for 11 000 samples in the bench fit's second iteration, 120 us in six
@@ -2525,7 +2526,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         // rank by counting; PARTS lanes share one element and split the comparisons
         int parts = 1;
         while (parts < 64 && k * parts * 2 <= NT) parts <<= 1;
-        const int per_part = (k + parts - 1) / parts;
+        const int per_part = (((k + parts - 1) / parts) + 3) & ~3; // (a multiple of four: the values are read four at a time)
+        const float4 *c4 = reinterpret_cast<const float4 *>(cnew);
         for (int t = tid; t < ((k * parts + NT - 1) / NT) * NT; t += NT) {
             const int j = t / parts, part = t % parts;
             int rank = 0;
@@ -2533,10 +2535,13 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             if (j < k) {
                 v = cnew[j];
                 const int i0 = part * per_part, i1 = min(k, i0 + per_part);
-#pragma unroll 8
-                for (int i = i0; i < i1; i++) {
-                    const float u = cnew[i];
-                    rank += (u < v) || (u == v && i < j);
+#pragma unroll 4
+                for (int i = i0; i < i1; i += 4) {
+                    const float4 u = c4[i >> 2];
+                    rank += (u.x < v) || (u.x == v && i < j);
+                    if (i + 1 < i1) rank += (u.y < v) || (u.y == v && i + 1 < j);
+                    if (i + 2 < i1) rank += (u.z < v) || (u.z == v && i + 2 < j);
+                    if (i + 3 < i1) rank += (u.w < v) || (u.w == v && i + 3 < j);
                 }
             }
             for (int off = 1; off < parts; off <<= 1) rank += __shfl_xor(rank, off);
@@ -2626,7 +2631,11 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             if (p < ku) {
                 const double cp = (double)cs[p];
                 double right = p + 1 < ku ? zhi[p] : INFINITY, left = p > 0 ? zlo[p] : -INFINITY;
-                for (int q = p + 2; q < ku; q++) { // pairs further apart matter only where centres crowd
+                // pairs further apart matter only where centres crowd; and there only the first few: a zone end is a minimum
+                // over pairs, so stopping early leaves it too far out -- a wider zone, a few more samples evaluated exactly --
+                // never wrong.  Without the cap a centre next to one float32 cannot tell it from goes through every pair up
+                // to a millimetre away: eighty evaluations one after the other behind a mass relocation (47 us of one step).
+                for (int q = p + 2; q < ku && q - p <= KM_ZONE_REACH; q++) {
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
                     const double delta = cq - cp;
@@ -2634,7 +2643,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                     const int d = q - p - 1;
                     if (delta > 0.0) right = fmin(right, d < zd ? zhi[d * ku + p] : km_pair_zone(cp, cq, xb).hi);
                 }
-                for (int q = p - 2; q >= 0; q--) {
+                for (int q = p - 2; q >= 0 && p - q <= KM_ZONE_REACH; q--) {
                     const double cq = (double)cs[q];
                     const double mid = 0.5 * (cp + cq);
                     const double delta = cp - cq;

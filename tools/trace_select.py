@@ -13,7 +13,7 @@ x = torch.from_numpy(synth.weights((n,), 4000)).to(dev)
 ops.prune_(x, 1.0, True)
 cdfs = pipeline.weight_distribution(x, True)
 space = pipeline.initial_centroids(x, 8, "density", cdfs)
-km = kmeans.DeviceKMeans(x, space)
+km = kmeans.DeviceKMeans(x, space, two_launch=True)
 tr = torch.zeros(8192, dtype=torch.int64, device=dev)
 names = ["inputs", "histogram cut", "survivors", "ranking", "proof", "edits"]
 for it in range(1, 30):
