@@ -4540,8 +4540,12 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
         for (int q = tid; q < ku; q += KM_THREADS) { zr_s[q] = tab->zr[q]; zl_s[q] = tab->zl[q]; }
         __syncthreads();
         // running maximum of the upper ends (from below) and running minimum of the lower ends (from above):
-        // Hillis-Steele over at most NNC_KMAX values, two per thread
-        for (int off = 1; off < ku; off <<= 1) {
+        // Hillis-Steele over at most NNC_KMAX values, two per thread -- unless the ends are in order already (no zone reaches
+        // across a neighbour's: the usual case away from a mass relocation), which one vote tells
+        int in_order = 1;
+        for (int q = tid; q + 1 < ku; q += KM_THREADS) in_order &= (zr_s[q + 1] >= zr_s[q]) && (zl_s[q] <= zl_s[q + 1]);
+        const int mono = __syncthreads_and(in_order);
+        for (int off = 1; off < ku && !mono; off <<= 1) {
             double a[2], b[2];
             for (int r = 0; r < 2; r++) {
                 const int q = tid + r * KM_THREADS;

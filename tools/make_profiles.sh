@@ -7,6 +7,8 @@ out=$PWD/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 python bench.py --steps 10 --warmup 2 > $out/bench_plain.json 2> $out/bench_plain.err
+python bench.py --steps 10 --warmup 2 --loop --no-cpu-baseline --no-streaming-leg > $out/bench_loop.json 2> $out/bench_loop.err
+NNC_DIAG=1 python tools/fit_only.py > $out/lloyd_phase_table_k257.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $CMD > $out/bench_under_trace.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $CMD > /dev/null 2>&1
