@@ -2114,6 +2114,9 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
     // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
     // to see its own tiles through.
+    // (a second look a moment later, for the passes the finalize step announces wide zones for, was measured: the one launch whose
+    // publisher comes late -- 75 tiles left to it and two or three late-comers -- drops from 50 to 30 us, the ten other announced
+    // launches of a bench step each pay 3.5 us for the pause: 0.1 ms worse per step)
     if (published || hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
     KBSTAMP(16 * j + 6, 0);
 }
