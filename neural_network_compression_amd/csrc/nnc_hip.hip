@@ -944,7 +944,7 @@ struct KmWs {
     // what k_bounds needs of the CURRENT table, at an address that does not depend on which of the two tables is current
     // (one round of loads less at the head of every iteration); k_finalize writes it next to tab[cur]
     struct Bnd { int32_t ku, pad; double zr[NNC_KMAX], zl[NNC_KMAX]; float2 cand[NNC_KMAX]; uint16_t orig[NNC_KMAX]; } bnd;
-    int32_t q_n, q_pad; // records published
+    int32_t q_n, q_searched; // records published; waves of an announced pass (help_hint) that are through their searches -- whatever they had to publish is out
     int32_t help_hint, help_pad; // the previous pass published long stretches: this one had better look at the queue (k_finalize sets it)
     long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
     unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
@@ -956,6 +956,7 @@ struct KmWs {
     unsigned long long kl_trace[24]; // diagnostics build: time per phase of k_lloyd (10 ns ticks), summed over the fit
     int32_t kl_stats[8]; // [0] iterations the loop ran, [1] its launches, [2] of them with centres changing places, [3] iterations handed over, [4] iterations the wide pair ran, [5] empty-cluster events the loop settled itself
     unsigned long long kl_keys[KL_RKEYS]; // candidate keys of such an event (kl_relocate)
+    int32_t bnd_phi[NNC_KMAX]; // per boundary j of the last k_bounds pass: the highest centre that could still win below U_j (the finalize step labels the undecided samples of an empty-cluster event with it, km_finalize_relocate)
     float kl_hL[2 * NNC_KMAX], kl_hR[2 * NNC_KMAX]; // per search (two a boundary: its ranks hint_a / hint_b): the threshold the rank was found for, the local density there (samples per unit)
     KmTab tab[2];
 };
@@ -1719,12 +1720,15 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
         const bool tie1 = tab->orig[plo + 1] < tab->orig[plo];
         long long s0 = 0, s1 = 0;
         unsigned n0 = 0, n1 = 0;
-        for (long long i0 = s; i0 < e; i0 += 256) { // four loads in flight per lane
-            float v[4];
+        // sixteen loads in flight per lane: a wave that is left alone with the tiles of a long stretch (its helpers looked at the
+        // queue before the record was out) is bound by the latency of these loads -- with four in flight a tile of 2048 samples took
+        // 8 us and the 75 tiles of one record of the bench fit 600 us whenever nobody came
+        for (long long i0 = s; i0 < e; i0 += 1024) {
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const long long i = i0 + lane + 64 * u; v[u] = i < e ? xs[i] : 0.0f; }
+            for (int u = 0; u < 16; u++) { const long long i = i0 + lane + 64 * u; v[u] = i < e ? xs[i] : 0.0f; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 16; u++) {
                 const long long i = i0 + lane + 64 * u;
                 if (i < e) {
                     const float xc = v[u] - mean;
@@ -1865,7 +1869,7 @@ __device__ __forceinline__ void km_bounds_preload(KmBndPre<BR> &p, const int j, 
 template <int BR>
 __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
                                                const KmTab *__restrict__ tab, const KmBndSrc src, const float mean, const int Sft,
-                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> *pre = nullptr)
+                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> *pre = nullptr, const int announced = 0)
 {
     bool published = false;
     // ---- one round of loads: every zone end (a lane holds those of the centres lane, lane + 64, ...; bounded by the caller's k,
@@ -1980,7 +1984,7 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
             }
         }
         const long long a = uni_ll(lo[0]), b = uni_ll(lo[1]), bm = uni_ll(lo[2]);
-        if (lane == 0) { ws->hint_a[j] = a; ws->hint_b[j] = b; }
+        if (lane == 0) { ws->hint_a[j] = a; ws->hint_b[j] = b; ws->bnd_phi[j] = phi; }
         KBSTAMP(16 * j + 3, 0);
         // ---- this centre's certain stretch [bm, a) and the undecided stretch above it, [max(a, bm), b): every load of both
         // goes out before anything is added up (the block prefixes, the two partial blocks, up to four undecided samples a lane)
@@ -2002,6 +2006,9 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
                 }
             }
         }
+        // (an announced pass: the others wait at the queue until every wave has said whether it had something to publish;
+        // release: the record above is out before the count)
+        if (announced && lane == 0) __hip_atomic_fetch_add(&ws->q_searched, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         float uv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (quick) {
 #pragma unroll
@@ -2074,10 +2081,12 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
             const int ntiles = (int)((e - s + tile - 1) / tile);
             int t = km_claim(&ws->q_next[r0 + b], lane);
             while (t < ntiles) {
+                const int tn = km_claim(&ws->q_next[r0 + b], lane); // (the next ticket is on its way while this tile is worked on: a
+                                                                    // wave left alone with a record is otherwise bound by the round trips)
                 const long long ts = s + (long long)t * tile;
                 const long long te = ts + tile < e ? ts + tile : e;
                 km_bounds_range(xs, ts, te, plo, phi, tab, ws, mean, Sft, lane);
-                t = km_claim(&ws->q_next[r0 + b], lane);
+                t = tn;
             }
         }
     }
@@ -2109,14 +2118,28 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     const int Sft = ws->p.fix_shift;
     if (stop | unasked) return;
     int qn_seen = 0; // the number of long stretches that were out when this wave's own loads went out
-    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, fixed_src ? &pre : nullptr);
+    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, fixed_src ? &pre : nullptr, hint == 2);
     KBSTAMP(16 * j + 5, 0);
     // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
     // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
     // to see its own tiles through.
-    // (a second look a moment later, for the passes the finalize step announces wide zones for, was measured: the one launch whose
-    // publisher comes late -- 75 tiles left to it and two or three late-comers -- drops from 50 to 30 us, the ten other announced
-    // launches of a bench step each pay 3.5 us for the pause: 0.1 ms worse per step)
+    // A wave whose boundary sits in a wide undecided interval searches a wider bracket and publishes its stretch microseconds after
+    // the others are through: its 75 tiles (bench fit, iteration 12: two centres 4e-8 apart at the edge of the pruned gap, 154 551
+    // samples between them) were then left to itself and whoever came late -- 30-140 us for the launch, 510-630 us when nobody
+    // came.  Where the finalize step has announced such an interval (help_hint), a wave therefore waits with its look at the queue
+    // until every wave of the pass is through its searches (q_searched: whatever there was to publish is out by then).  Nobody's
+    // PROGRESS depends on this -- a publisher sees its own tiles through alone if need be -- and the number of looks is bounded,
+    // so the loop ends whatever the others do.  Cost: the pass lasts as long as its slowest search plus one look (+ 4 us).
+    // (One wave of every workgroup waits and helps, the others leave: 260 waves polling one word cost each announced pass 9 us.)
+    const bool waits = hint == 2 && !published && fixed_src;
+    if (waits && (threadIdx.x >> 6) != 0 && uni_i(qn_seen) == 0) return;
+    if (waits) {
+        const int nwaves = pre.ku;
+        for (int look = 0; look < 128; look++) {
+            if (km_peek_i(&ws->q_searched) >= nwaves) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
     if (published || hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
     KBSTAMP(16 * j + 6, 0);
 }
@@ -2267,6 +2290,18 @@ __device__ __forceinline__ KmZone km_pair_zone(const double cp, const double cq,
 // how far the crossing point of a pair can lie from its midpoint at most (for the early exit of the loops over the pairs)
 __device__ __forceinline__ double km_pair_slack(const double delta, const double xb) { return 1.25e-7 * xb * xb * km_rcp_up(delta); }
 
+__device__ __forceinline__ unsigned f32_ordered_bits(float x)
+{
+    const unsigned u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // unsigned order == float order
+}
+__device__ __forceinline__ float f32_from_ordered_bits(unsigned o)
+{
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+#include "nnc_lloyd.hpp"
+
 // workgroup barrier that orders LDS traffic only (see km_finalize_body)
 __device__ __forceinline__ void km_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 // workgroup votes through an LDS word that starts at zero and is used once per launch
@@ -2284,13 +2319,81 @@ __device__ __forceinline__ int km_vote_count(int *word, const int x) // threads 
     return *word;
 }
 
+// An empty-cluster event of a rank-boundary iteration settled by the finalize step itself -- kl_relocate, the selection the
+// resident loop uses (nnc_lloyd.hpp), fed from what the k_bounds pass of this iteration left in the workspace: its ranks a_j / b_j
+// (hint_a / hint_b), the candidate range of every undecided stretch (bnd_phi), the centres it labelled against (tab).  The chain
+// of four launches behind the iteration (or, outside the batches that carry one, the host's look-in, its windowed relocation
+// and the rest of a batch gone idle) is then not needed.  Returns 1 when the sums in sum_o / cnt_o have been edited and the step
+// goes on as if resumed; 0 when the event is not one for this path (more than KL_RM_MAX empty clusters, long undecided
+// stretches, no proof, ...): nothing has changed and the step pauses as before.
+template <int NT>
+__device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restrict__ xs, const long long n, const KmTab *__restrict__ tab, const int ku,
+                                    const int k, const int cur, long long *sum_o, long long *cnt_o, const float mean, const int Sft)
+{
+    constexpr int KC = NNC_KMAX;
+    __shared__ __align__(16) unsigned char buf[sizeof(KlHead) + (size_t)KC * (8 + 8 + 4 + 4 + 4 + 4 + 2 + 2) + 4096 * 2];
+    KlHead *hd = reinterpret_cast<KlHead *>(buf);
+    KlArr L = {};
+    {
+        unsigned char *q = buf + sizeof(KlHead);
+        L.A = reinterpret_cast<long long *>(q); q += (size_t)KC * 8;
+        L.B = reinterpret_cast<long long *>(q); q += (size_t)KC * 8;
+        L.cs = reinterpret_cast<float *>(q); q += (size_t)KC * 4;
+        L.csq = reinterpret_cast<float *>(q); q += (size_t)KC * 4;
+        L.cold = reinterpret_cast<float *>(q); q += (size_t)KC * 4;
+        L.call = reinterpret_cast<float *>(q); q += (size_t)KC * 4; // (the chunk list's first-chunk table)
+        L.so = reinterpret_cast<uint16_t *>(q); q += (size_t)KC * 2;
+        L.phi = reinterpret_cast<uint16_t *>(q); q += (size_t)KC * 2;
+        L.qj = reinterpret_cast<uint16_t *>(q);
+    }
+    const int tid = threadIdx.x;
+    if (tid == 0) { hd->n_empty = 0; hd->ku = ku; hd->nch = 0; hd->slow = 0; hd->r_flat = 0; }
+    __syncthreads();
+    int e = 0;
+    for (int j = tid; j < k; j += NT) { e += cnt_o[j] == 0; L.cold[j] = ws->c[cur][j]; }
+    if (e) atomicAdd(&hd->n_empty, e);
+    __syncthreads();
+    if (hd->n_empty > KL_RM_MAX || 2 * ku > NT) return 0; // (not an event for this path: leave before the tables are fetched)
+    for (int p = tid; p < ku; p += NT) {
+        const float2 c = tab->cand[p];
+        L.cs[p] = c.x; L.csq[p] = c.y; L.so[p] = tab->orig[p];
+        L.A[p] = ws->hint_a[p]; L.B[p] = ws->hint_b[p];
+        const int ph = ws->bnd_phi[p];
+        L.phi[p] = (uint16_t)(ph < p + 1 ? p + 1 : (ph > ku - 1 ? ku - 1 : ph));
+    }
+    __syncthreads();
+    // the chunks of the undecided stretches, as kl_chunks cuts them (a long stretch -- a run of equal values, two centres float32
+    // cannot tell apart -- makes the event the chain's)
+    int *qfirst = reinterpret_cast<int *>(L.call);
+    for (int j = tid; j + 1 < ku; j += NT) {
+        const long long bm = j > 0 ? L.B[j - 1] : 0, a = L.A[j], b = L.B[j];
+        const long long s0 = a > bm ? a : bm;
+        const long long len = b - s0;
+        qfirst[j] = 0;
+        if (len > 0) {
+            const int cs_ = (int)L.phi[j] == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
+            const long long nc = (len + cs_ - 1) / cs_;
+            if (nc > 16) hd->slow = 1;
+            else {
+                const int first = atomicAdd(&hd->nch, (int)nc);
+                qfirst[j] = first;
+                for (int i = 0; i < (int)nc; i++) if (first + i < KL_QMAX) L.qj[first + i] = (uint16_t)j;
+            }
+        }
+    }
+    __syncthreads();
+    if (hd->slow || hd->nch > 256) return 0;
+    return kl_relocate<NT>(xs, n, ws, hd, L, sum_o, cnt_o, k, hd->nch, mean, Sft);
+}
+
 // NT threads: a fit with few centres runs it as a single wave (64) or four (256), for which the many barriers and
 // wave-to-wave hand-overs of the scans cost next to nothing; NT >= k is all it needs (k > 1024 takes two rounds of 1024).
 // WAVE (NT == 64 only): the body is run by ONE wave of a larger workgroup, so it may not use workgroup barriers; the
 // wave's own lock step (plus a compiler fence) orders its LDS traffic.  Returns true if new zones were left
 // (gcell / hcell / ku_out = {ku, cur} filled), i.e. the cell table has to be rebuilt.
 template <int NT, bool ONEWAVE>
-__device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out, const bool lazy = false)
+__device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out, const bool lazy = false,
+                                                 const float *__restrict__ reloc_xs = nullptr, const long long reloc_n = 0)
 {
     static_assert(!ONEWAVE || NT == 64, "the barrier-free form is for a single wave");
     // The threads of this step talk to each other through LDS only; what they write to global memory is for later kernels.  A
@@ -2321,11 +2424,15 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     FSTAMP(0);
     if (tid == 0) ws->cells_pending = 0;
     if (!ONEWAVE && tid < 8) fin_votes[tid] = 0; // (the barrier below is in front of the first vote)
-    {   // the tile queue of the pass that produced these sums (k_bounds) is spent
-        const int qn = min(ws->q_n, (int)NNC_KMAX);
+    {   // the tile queue of the pass that produced these sums (k_bounds) is spent -- for the call that takes the sums of a pass; a
+        // call that resumes behind a relocation (or finds it has nothing to do: the resume of a chain enqueued "in case") leaves
+        // the queue and above all the announcement for the next pass alone (until round 3 the idle resume behind every iteration of
+        // a batch with chains wiped it: the passes that most needed helpers at the queue went without)
+        const bool takes_a_pass = mode != FIN_FROM_PARTIALS || !resume;
+        const int qn = takes_a_pass ? min(ws->q_n, (int)NNC_KMAX) : 0;
         for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
-        if (tid == 0) { ws->q_n = 0; ws->help_hint = qn > 0; }
+        if (tid == 0 && takes_a_pass) { ws->q_n = 0; ws->q_searched = 0; ws->help_hint = qn > 0; }
     }
     // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
     // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
@@ -2400,6 +2507,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         for (int j = tid; j < k; j += NT) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
     FIN_SYNC();
+    int same_counts_now = 0;
+    bool settled_event = false; // an empty-cluster event was settled in this very call (km_finalize_relocate)
     if (track) {
         int count_diff = 0;
 #pragma unroll
@@ -2412,6 +2521,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             }
         }
         const int any_diff = FIN_OR(0, count_diff);
+        same_counts_now = any_diff ? 0 : 1;
         if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
     }
     FSTAMP(1);
@@ -2421,7 +2531,18 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         int my_empty = 0;
         for (int j = tid; j < k; j += NT) my_empty += (cnt_o[j] == 0);
         if (tid == 0) sh_key = 0ull;
-        const int n_empty = FIN_COUNT(1, my_empty);
+        int n_empty = FIN_COUNT(1, my_empty);
+        bool settled = false;
+        settled_event = false;
+        if constexpr (!ONEWAVE) {
+            // (the same conditions under which the chain enqueued "in case" goes ahead: km_spec_decide)
+            if (n_empty > 0 && !resume && reloc_xs && mode == FIN_FROM_SHARDS && lazy && !(st_iter >= 1 && same_counts_now)) {
+                __syncthreads(); // (the global stores of this step so far are out before the selection reads the workspace)
+                const KmTab *tabc = &ws->tab[cur];
+                settled = km_finalize_relocate<NT>(ws, reloc_xs, reloc_n, tabc, cur ? ku1 : ku0, k, cur, sum_o, cnt_o, ws->p.x_mean, Sft) != 0;
+                if (settled) { n_empty = 0; settled_event = true; }
+            }
+        }
         if (n_empty > 0 && !resume) {
             int tot_empty = 0;
             if (tid == 0) {
@@ -2658,7 +2779,14 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                 ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
                 // a zone wide enough to hold thousands of samples (two centres float32 can hardly tell apart): the coming pass will
                 // publish a long undecided stretch, and every wave of it had better look at the tile queue when its own work is done
-                if (p > 0 && p + 1 < ku && (right - left) * (double)n_tot * 4.0 > (double)KM_TILE * ((double)p_hi - (double)p_lo)) wide_zone = 1;
+                // An UNDECIDED interval wide enough to hold thousands of samples (two centres float32 can hardly tell apart: what
+                // neither neighbour can be ruled out on is the overlap of their zones, zr[p] - zl[p + 1], here by the pair's own
+                // interval): the coming pass will publish a long stretch, and its waves had better look at the tile queue -- twice
+                // (k_bounds).  (Until round 3 the test was on the centre's whole zone, its cell included: true for every centre,
+                // so every wave of every pass paid the look.)
+                // (announced from sixteen tiles' worth up, at four times the mean density: the announcement costs the pass some
+                // 8 us of waiting at the queue; a publisher left alone with fewer tiles than that costs less)
+                if (p + 1 < ku && (zhi[p] - zlo[p + 1]) * (double)n_tot * 4.0 > 16.0 * (double)KM_TILE * ((double)p_hi - (double)p_lo)) wide_zone = 1;
                 gp = G - 1; hp_ = 0;
                 if (inv > 0.0 && !lazy) {
                     const double qa = (right - lo) / ra; // may be +-inf
@@ -2675,7 +2803,12 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             if (p < ku) { gcell[p] = gp; hcell[p] = hp_; }
         }
         FSTAMP(15);
-        if (FIN_OR(6, wide_zone) && tid == 0) ws->help_hint = 1;
+        // (2: the coming pass waits at the queue until every wave has searched; 1: one look.  A wide interval appears out of
+        // nothing only where centres were just placed -- the first pass, the pass behind a relocation: two of them a few ulps
+        // apart; one that grows as two centres drift together is seen a pass late through the records it published, and while it
+        // is still a few tiles long that costs little)
+        const bool placed = mode == FIN_INIT || resume || settled_event;
+        if (FIN_OR(6, wide_zone) && tid == 0 && placed) ws->help_hint = 2;
         FIN_SYNC();
         FSTAMP(11);
         if (!lazy) { // (the rank-boundary iterations do not use the cell side of the zones: k_cells works it out on demand)
@@ -2761,7 +2894,8 @@ __device__ __forceinline__ uint16_t km_cell_entry(int g, int G, int ku, const in
 template <int NT, bool FUSED>
 __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume,
                                                                       nnc_kmeans_status *host_st, unsigned long long *host_ticket,
-                                                                      unsigned long long ticket, int lazy)
+                                                                      unsigned long long ticket, int lazy, const float *__restrict__ reloc_xs,
+                                                                      long long reloc_n)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
     __shared__ int fin_go, fin_kc[2], fin_novf; // fin_kc: {distinct centres, current table} from the body
@@ -2780,7 +2914,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
         if (tid == 0) { fin_go = 0; fin_novf = 0; }
         __syncthreads();
         if (tid < NT) {
-            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0);
+            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n);
             if (tid == 0) __hip_atomic_store(&fin_go, (built && !lazy) ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         int go; // every path of the body ends in the store above, so the wait is bounded by the body's run time
@@ -2793,7 +2927,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
             if (tid == 0) tab->n_ovf = fin_novf;
         }
     } else {
-        km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0);
+        km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n);
     }
     if (cond && fin_asked) { // the iteration k_lloyd handed over has been run (or has paused): the loop may go on
         __syncthreads();
@@ -2931,17 +3065,6 @@ __global__ __launch_bounds__(KM_THREADS) void k_cells(KmWs *__restrict__ ws, nnc
     km_cells_body(ws, host_st, host_ticket, ticket, force, which, spec, (int)blockIdx.x);
 }
 
-__device__ __forceinline__ unsigned f32_ordered_bits(float x)
-{
-    const unsigned u = __float_as_uint(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u); // unsigned order == float order
-}
-__device__ __forceinline__ float f32_from_ordered_bits(unsigned o)
-{
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
-}
-
-#include "nnc_lloyd.hpp"
 
 static bool km_fused(const nnc_kmeans_params *p)
 {
@@ -2968,8 +3091,10 @@ static int km_ensure_cells(KmWs *w, const nnc_kmeans_params *p, int which, void 
     return NNC_OK;
 }
 
+// reloc_xs: the value-sorted vector, for callers that want the finalize step of a rank-boundary iteration to settle small
+// empty-cluster events itself (km_finalize_relocate: nnc_kmeans_fit); nullptr: every event pauses (what nnc_kmeans_iterate shows)
 static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume, void *stream, void *host_mapped = nullptr,
-                              uint64_t ticket = 0, bool cond = false)
+                              uint64_t ticket = 0, bool cond = false, const float *reloc_xs = nullptr)
 {
     // p == nullptr: the caller does not know the fit's parameters (nnc_kmeans_finalize): full width, k_cells builds the table
     const int k = p ? p->k : 0;
@@ -2981,7 +3106,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
     nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
-#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0))
+#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0), reloc_xs, (long long)(p ? p->n : 0))
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
     else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256); // (measured at K = 257: one wave 23.6 us, four waves 14.6 / 17.7 us median / mean, sixteen 14.4 / 15.9)
@@ -3024,7 +3149,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->partials[i] = 0; ws->partials_local[i] = 0; }
     for (int i = tid; i < NNC_KMAX; i += KM_THREADS) { ws->prev_counts[i] = -1; ws->q_w0[i] = 0ull; ws->q_w1[i] = 0ull; ws->q_next[i] = 0; ws->hint_a[i] = -1; ws->hint_b[i] = -1; }
     for (int i = tid; i < 2 * NNC_KMAX; i += KM_THREADS) { ws->kl_hL[i] = 0.0f; ws->kl_hR[i] = 0.0f; }
-    if (tid == 0) { ws->q_n = 0; ws->help_hint = 0; ws->help_pad = 0; ws->wide = 0; ws->kl_budget = 0; }
+    if (tid == 0) { ws->q_n = 0; ws->q_searched = 0; ws->help_hint = 0; ws->help_pad = 0; ws->wide = 0; ws->kl_budget = 0; }
     if (tid < 8) ws->kl_stats[tid] = 0;
     if (tid < 24) ws->kl_trace[tid] = 0ull;
 }
@@ -3381,8 +3506,17 @@ extern "C" int nnc_kmeans_label_counts(const float *x, void *ws, const nnc_kmean
     return NNC_OK;
 }
 
+static int km_iterate_publish_(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped, uint64_t ticket, void *stream,
+                               bool reloc_in_place);
 extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped,
                                           uint64_t ticket, void *stream)
+{
+    return km_iterate_publish_(x, ws, pp, iters, host_mapped, ticket, stream, false); // (a caller of this entry point sees every pause)
+}
+
+// reloc_in_place: x is the value-sorted vector and the finalize step may settle small empty-cluster events itself
+static int km_iterate_publish_(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped, uint64_t ticket, void *stream,
+                               bool reloc_in_place)
 {
     int rc = km_check(ws, pp, "nnc_kmeans_iterate_publish");
     if (rc) return rc;
@@ -3410,7 +3544,8 @@ extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_km
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
         const bool last = i == iters - 1;
-        if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
+        if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket, false,
+                                     (reloc_in_place && p.prefix_dev) ? x : nullptr))) return rc;
     }
     return NNC_OK;
 }
@@ -4825,10 +4960,10 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
             if ((rc = km_set_lds_attr())) return rc;
             for (int i = 0; i < batch; i++) {
                 if ((rc = km_launch_accumulate(x_iter, w, &p, stream))) return rc;
-                if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream))) return rc;
+                if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream, nullptr, 0, false, x_iter))) return rc; // (small events: in place)
                 if ((rc = km_launch_spec_reloc(x_iter, w, &p, reloc_scratch_dev, stream, i == batch - 1 ? sl : nullptr, ticket))) return rc;
             }
-        } else if ((rc = nnc_kmeans_iterate_publish(x_iter, ws, &p, batch, sl, ticket, stream))) return rc;
+        } else if ((rc = km_iterate_publish_(x_iter, ws, &p, batch, sl, ticket, stream, spec_ok))) return rc;
         if ((rc = km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(sl + sizeof(nnc_kmeans_status)), ticket, S(stream)))) return rc;
         const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
         *status_out = st;

@@ -707,21 +707,40 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
     __syncthreads();
     // ---- the ends of the certain stretches: group q = (centre p, lower / upper end), one sample a lane, the outermost first
     unsigned inner = 0u; // the largest distance of an innermost candidate that has samples behind it
-    for (int q = g; q < 2 * ku; q += NT / 8) {
-        const int p = q >> 1, side = q & 1;
-        const long long lo_r = p > 0 ? L.B[p - 1] : 0, hi_r = p == ku - 1 ? n : L.A[p];
-        long long r = -1;
-        if (side == 0) { r = lo_r + gl; if (r >= hi_r) r = -1; }
-        else { r = hi_r - 1 - gl; if (r < lo_r + KL_RW) r = -1; } // (a short stretch: its first KL_RW samples are the lower end's)
-        unsigned long long key = 0ull;
-        if (r >= 0) {
-            const float xv = xs[r];
-            const float dd = (xv - mean) - L.cs[p];
-            const float dv = dd * dd;
-            key = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
-            if (gl == KL_RW - 1 && hi_r - lo_r > 2 * KL_RW) inner = max(inner, __float_as_uint(dv));
+    {   // (2 ku <= NT: at most eight groups a thread; all their samples are fetched before any is looked at)
+        long long rr[8];
+        float xq[8];
+        bool deep[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = g + u * (NT / 8);
+            rr[u] = -1; deep[u] = false;
+            if (q < 2 * ku) {
+                const int p = q >> 1, side = q & 1;
+                const long long lo_r = p > 0 ? L.B[p - 1] : 0, hi_r = p == ku - 1 ? n : L.A[p];
+                long long r = -1;
+                if (side == 0) { r = lo_r + gl; if (r >= hi_r) r = -1; }
+                else { r = hi_r - 1 - gl; if (r < lo_r + KL_RW) r = -1; } // (a short stretch: its first KL_RW samples are the lower end's)
+                rr[u] = r;
+                deep[u] = gl == KL_RW - 1 && hi_r - lo_r > 2 * KL_RW;
+            }
         }
-        keys[q * KL_RW + gl] = key;
+#pragma unroll
+        for (int u = 0; u < 8; u++) xq[u] = rr[u] >= 0 ? xs[rr[u]] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = g + u * (NT / 8);
+            if (q < 2 * ku) {
+                unsigned long long key = 0ull;
+                if (rr[u] >= 0) {
+                    const float dd = (xq[u] - mean) - L.cs[q >> 1];
+                    const float dv = dd * dd;
+                    key = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xq[u]);
+                    if (deep[u]) inner = max(inner, __float_as_uint(dv));
+                }
+                keys[q * KL_RW + gl] = key;
+            }
+        }
     }
     // ---- the undecided stretches, chunk by chunk as kl_label went through them: exact label, then the distance to that centre
     const int *qfirst = reinterpret_cast<const int *>(L.call);

@@ -190,3 +190,29 @@ def test_empty_clusters_are_settled_inside_the_loop(km):
         events += a.n_relocations_
         assert st["relocated_in_loop"] <= a.n_relocations_
     assert events > 0 and in_loop > 0, (events, in_loop)
+
+
+def test_finalize_step_settles_small_events_itself(km):
+    """The launch-per-iteration form under fit(): the finalize step relocates the far samples of a small empty-cluster event itself
+    (km_finalize_relocate: the selection of the resident loop, fed from the ranks k_bounds left) -- same trajectory as the oracle, and
+    as the loop; stepping with iterate_and_look still shows every pause."""
+    for n, k, seed in [(235_200, 32, 1), (627_200, 33, 4), (500_000, 257, 6), (300_000, 300, 8), (120_000, 64, 7)]:
+        x = _pruned(n, 900 + seed)
+        init = _init(x, k, "forgy", seed)
+        t = torch.from_numpy(x).cuda()
+        b, bv = km.DeviceKMeans(t, init, two_launch=True).fit()
+        ob = orc.kmeans_lloyd(x, init, accum="B")
+        assert b.n_iter_ == ob.n_iter_ and np.array_equal(b.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), (n, k, seed)
+        assert np.array_equal(b.labels_, ob.labels_)
+        assert b.n_relocations_ == ob.reloc_info_.get("reloc_events", 0), (b.n_relocations_, ob.reloc_info_)
+        # stepping: the pauses are the host's to see
+        d = km.DeviceKMeans(t, init, two_launch=True)
+        seen = 0
+        for _ in range(60):
+            st = d.iterate_and_look(1)
+            if st.done:
+                break
+            if st.paused:
+                seen += 1
+                d._relocate_and_resume(st)
+        assert seen == b.n_relocations_, (seen, b.n_relocations_)

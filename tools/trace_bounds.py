@@ -19,6 +19,7 @@ trace = torch.zeros(8192, dtype=torch.int64, pin_memory=True)
 it = 0
 while True:
     if it in target:
+        cen_before = np.sort(np.unique(km.centers(centred=True)))
         nat.check(L.nnc_debug_set_trace(trace.data_ptr()))
     s = km.iterate_and_look(1)
     torch.cuda.synchronize()
@@ -37,6 +38,10 @@ while True:
         worst = np.argsort(rel[:, 6])[-3:]
         for w in worst:
             print("   slow wave", int(np.nonzero(act)[0][w]), [round(float(v), 2) for v in rel[w]], "undecided", int(und[w]), "candidates", int(ncand[w]), "certain", int(sure[w]))
+        jm = int(np.argmax(und)); jj = int(np.nonzero(act)[0][jm])
+        lo_, hi_ = max(0, jj - 2), min(len(cen_before), jj + 4)
+        print("   longest stretch: wave", jj, "undecided", int(und[jm]), "candidates", int(ncand[jm]), "distinct centres", len(cen_before),
+              "centres around it", [float(v) for v in cen_before[lo_:hi_]], "gaps", [float(v) for v in np.diff(cen_before[lo_:hi_])])
         print("   undecided total", int(und[:-4].sum()), "; waves with > 2 candidates:", int((ncand[:-4] > 2).sum()), "max candidates", int(ncand[:-4].max()))
         trace.zero_()
     if s.paused:
