@@ -228,6 +228,9 @@ typedef struct nnc_kmeans_status {
     int32_t n_relocated; /* relocation events the device settled without the host (nnc_kmeans_fit enqueues the windowed relocation
                             behind the iterations of a batch in case they pause; it does nothing when they do not) */
     int32_t n_unproven;  /* ... and the events such a chain met but could not prove (the fit then pauses with paused == 2) */
+    int32_t n_in_place;  /* of n_relocated: the events settled inside an iteration's own launch (the resident loop, or the finalize
+                            step of a rank-boundary pass: small events, no relocation chain needed) */
+    int32_t reserved;
 } nnc_kmeans_status;
 
 int32_t nnc_fix_shift(float absmax, int64_t n_total);

@@ -50,6 +50,7 @@ class KMeansStatus(ctypes.Structure):
         ("iter", c_i32), ("done", c_i32), ("paused", c_i32), ("n_empty", c_i32),
         ("shift_tot", c_f32), ("tol", c_f32), ("k", c_i32), ("same_counts", c_i32),
         ("reloc_ties", c_i32), ("reloc_multi", c_i32), ("n_relocated", c_i32), ("n_unproven", c_i32),
+        ("n_in_place", c_i32), ("reserved", c_i32),
     ]
 
 

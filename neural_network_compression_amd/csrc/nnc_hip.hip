@@ -3136,7 +3136,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid == 0) {
         ws->st.iter = 0; ws->st.done = 0; ws->st.paused = 0; ws->st.n_empty = 0;
         ws->st.shift_tot = 0.0f; ws->st.tol = p.tol; ws->st.k = p.k; ws->st.same_counts = 0;
-        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0; ws->st.n_relocated = 0; ws->st.n_unproven = 0; ws->spec_go = 0;
+        ws->st.reloc_ties = 0; ws->st.reloc_multi = 0; ws->st.n_relocated = 0; ws->st.n_unproven = 0; ws->st.n_in_place = 0; ws->st.reserved = 0; ws->spec_go = 0;
         ws->p = p; ws->cur = 0; ws->glog2 = glog2; ws->rlog2 = rlog2; ws->inv = inv; ws->reloc_fail = 0; ws->cells_pending = 0;
     }
     for (int j = tid; j < p.k; j += KM_THREADS) {
@@ -4937,11 +4937,13 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
     const bool spec_ok = sorted && !one_launch && p.prefix_dev && reloc_scratch_dev && (reinterpret_cast<uintptr_t>(reloc_scratch_dev) & 255) == 0 &&
                          reloc_scratch_bytes >= nnc_kmeans_reloc_scratch_bytes(p.k, KM_SPEC_WMAX) && p.n >= 2 * KM_SPEC_WMAX;
     bool spec = spec_ok;
-    int batch = one_launch ? p.max_iter : (spec ? 12 : 1); // the first iteration is where duplicate initial centres surface as empty clusters
+    int batch = one_launch ? p.max_iter : (spec ? 6 : 1); // the first iteration is where duplicate initial centres surface as empty clusters
+                                                           // (six with chains: the mass events come first; small ones need no chain)
     if (lloyd) batch = KM_LLOYD_ROUNDS; // rounds per look-in: a round ends at an empty cluster (settled by the chain behind it, if there is one) or a handed-over iteration
     bool first_launch = true;
     int nwin = 0, nrel_seen = status_out->n_relocated, nunp_seen = status_out->n_unproven; // (a call after a full-pass relocation carries on from the last status)
-    if (!spec_ok) { nrel_seen = 0; nunp_seen = 0; }
+    int nip_seen = status_out->n_in_place;
+    if (!spec_ok) { nrel_seen = 0; nunp_seen = 0; nip_seen = 0; }
     double s_prev = -1.0, s_last = -1.0;
     int i_prev = 0, i_last = 0;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
@@ -4968,7 +4970,9 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
         const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
         *status_out = st;
         const int dev_events = spec_ok ? st.n_relocated - nrel_seen : 0; // events the device settled by itself in this batch
+        const int chain_events = dev_events - (spec_ok ? st.n_in_place - nip_seen : 0); // ... of them by a chain enqueued in case
         nrel_seen = st.n_relocated;
+        nip_seen = st.n_in_place;
         nwin += dev_events;
         // an unproven windowed selection comes back as paused == 2 and the caller takes one windowed event back before it redoes
         // it in full: the attempts of the chains enqueued "in case" are counted like the ones this loop asks for itself
@@ -4979,7 +4983,8 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
         if (spec && !st.paused) {
             // a chain that finds nothing to do still costs its five launches (about as much as the round trip it would have saved):
             // carry on only while most iterations pause
-            if (2 * dev_events >= batch) { batch = 4; s_prev = s_last = -1.0; continue; }
+            // (events the iterations settle in their own launch do not need one)
+            if (2 * chain_events >= batch) { batch = 4; s_prev = s_last = -1.0; continue; }
             spec = false; // back to plain iterations, sized by the decay of the shift
             s_prev = s_last = -1.0;
         }

@@ -878,6 +878,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
             const unsigned long long kn = hd->r_keys[m];
             if (kn != 0ull && (kn >> 32) == (kcut >> 32) && kn != kcut) ws->st.reloc_ties += 1;
             ws->st.n_relocated += 1; // (the host does not see this event: it counts them from here)
+            ws->st.n_in_place += 1;
             ws->reloc_fail = 0;
             ws->kl_stats[5] += 1;
         }
