@@ -208,7 +208,7 @@ typedef struct nnc_kmeans_params {
  * NNC_KM_LOOP_KMAX centres, where one compute unit's instruction rate is not yet the bound: measured on 0.1 M - 25 M weights it
  * takes 0.46 - 0.8 of the launch-per-iteration time up to K = 65, about the same at K = 129, 1.0 - 1.2 of it at K = 257). */
 #define NNC_KM_LOOP 2
-#define NNC_KM_LOOP_KMAX 192
+#define NNC_KM_LOOP_KMAX 64
 
 typedef struct nnc_kmeans_status {
     int32_t iter;      /* completed Lloyd iterations (scikit-learn's n_iter_ when done) */

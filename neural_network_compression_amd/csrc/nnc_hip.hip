@@ -1869,19 +1869,19 @@ __device__ __forceinline__ void km_bounds_preload(KmBndPre<BR> &p, const int j, 
 template <int BR>
 __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
                                                const KmTab *__restrict__ tab, const KmBndSrc src, const float mean, const int Sft,
-                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> *pre = nullptr, const int announced = 0)
+                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> &pre, const int announced = 0)
 {
     bool published = false;
     // ---- one round of loads: every zone end (a lane holds those of the centres lane, lane + 64, ...; bounded by the caller's k,
     // which is known before anything has arrived), the number of distinct centres, the two centres either side of this
     // wave's boundary, where the boundaries were last time
-    KmBndPre<BR> own;
-    if (!pre) { km_bounds_preload<BR>(own, j, lane, ws, src); pre = &own; }
-    const double (&zrv)[BR] = pre->zrv, (&zlv)[BR] = pre->zlv;
-    const float2 cj0 = pre->cj0, cj1r = pre->cj1r;
-    const int oj0 = pre->oj0, oj1r = pre->oj1r;
-    const long long hint_a = pre->hint_a, hint_b = pre->hint_b, hint_bm = pre->hint_bm;
-    const int ku = pre->ku;
+    // (by reference to ONE block the caller filled: through a pointer that could point to either of two blocks the arrays lived in
+    // scratch memory -- 136 bytes a lane at K = 257, every access a trip to memory)
+    const double (&zrv)[BR] = pre.zrv, (&zlv)[BR] = pre.zlv;
+    const float2 cj0 = pre.cj0, cj1r = pre.cj1r;
+    const int oj0 = pre.oj0, oj1r = pre.oj1r;
+    const long long hint_a = pre.hint_a, hint_b = pre.hint_b, hint_bm = pre.hint_bm;
+    const int ku = pre.ku;
     if (j < ku) {
         // ---- the zone ends that bound this wave's stretches
         double Uj = -INFINITY, Ujm1 = -INFINITY, Lj = INFINITY;
@@ -2118,7 +2118,8 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     const int Sft = ws->p.fix_shift;
     if (stop | unasked) return;
     int qn_seen = 0; // the number of long stretches that were out when this wave's own loads went out
-    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, fixed_src ? &pre : nullptr, hint == 2);
+    if (!fixed_src) km_bounds_preload<BR>(pre, j, lane, ws, src);
+    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, pre, hint == 2);
     KBSTAMP(16 * j + 5, 0);
     // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
     // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
@@ -2353,7 +2354,7 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
     for (int j = tid; j < k; j += NT) { e += cnt_o[j] == 0; L.cold[j] = ws->c[cur][j]; }
     if (e) atomicAdd(&hd->n_empty, e);
     __syncthreads();
-    if (hd->n_empty > KL_RM_MAX || 2 * ku > NT) return 0; // (not an event for this path: leave before the tables are fetched)
+    if (hd->n_empty > KL_RM_MAX || 2 * ku > KL_RPASS * (NT / 8)) return 0; // (not an event for this path: leave before the tables are fetched)
     for (int p = tid; p < ku; p += NT) {
         const float2 c = tab->cand[p];
         L.cs[p] = c.x; L.csq[p] = c.y; L.so[p] = tab->orig[p];
@@ -2538,9 +2539,11 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             // (the same conditions under which the chain enqueued "in case" goes ahead: km_spec_decide)
             if (n_empty > 0 && !resume && reloc_xs && mode == FIN_FROM_SHARDS && lazy && !(st_iter >= 1 && same_counts_now)) {
                 __syncthreads(); // (the global stores of this step so far are out before the selection reads the workspace)
+                if (ftr && tid == 0) { ftr[20] = ftr[0]; ftr[21] = __builtin_amdgcn_s_memrealtime(); }
                 const KmTab *tabc = &ws->tab[cur];
                 settled = km_finalize_relocate<NT>(ws, reloc_xs, reloc_n, tabc, cur ? ku1 : ku0, k, cur, sum_o, cnt_o, ws->p.x_mean, Sft) != 0;
                 if (settled) { n_empty = 0; settled_event = true; }
+                if (settled && ftr && tid == 0) ftr[22] = __builtin_amdgcn_s_memrealtime();
             }
         }
         if (n_empty > 0 && !resume) {
@@ -2661,11 +2664,13 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
                 const int i0 = part * per_part, i1 = min(k, i0 + per_part);
 #pragma unroll 4
                 for (int i = i0; i < i1; i += 4) {
+                    // (bit operations, not || and &&: the short-circuit form compiled to a branch per comparison, some twenty-five
+                    // instructions an element -- 66 000 comparisons at K = 257 made this loop 7 us of every resumed step)
                     const float4 u = c4[i >> 2];
-                    rank += (u.x < v) || (u.x == v && i < j);
-                    if (i + 1 < i1) rank += (u.y < v) || (u.y == v && i + 1 < j);
-                    if (i + 2 < i1) rank += (u.z < v) || (u.z == v && i + 2 < j);
-                    if (i + 3 < i1) rank += (u.w < v) || (u.w == v && i + 3 < j);
+                    rank += (int)(u.x < v) | ((int)(u.x == v) & (int)(i < j));
+                    rank += ((int)(u.y < v) | ((int)(u.y == v) & (int)(i + 1 < j))) & (int)(i + 1 < i1);
+                    rank += ((int)(u.z < v) | ((int)(u.z == v) & (int)(i + 2 < j))) & (int)(i + 2 < i1);
+                    rank += ((int)(u.w < v) | ((int)(u.w == v) & (int)(i + 3 < j))) & (int)(i + 3 < i1);
                 }
             }
             for (int off = 1; off < parts; off <<= 1) rank += __shfl_xor(rank, off);
@@ -2674,6 +2679,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     }
     FIN_SYNC();
     FSTAMP(9);
+    if (settled_event && ftr && tid == 0) { ftr[23] = ftr[3]; ftr[24] = ftr[9]; }
     // Equal centres: the first one (lowest original index; the sort breaks ties that way) takes every
     // tie, the others can never win.  Keep only distinct values in the search tables.
     int ku = 0;
@@ -2811,6 +2817,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         if (FIN_OR(6, wide_zone) && tid == 0 && placed) ws->help_hint = 2;
         FIN_SYNC();
         FSTAMP(11);
+        if (settled_event && ftr && tid == 0) ftr[25] = ftr[11];
         if (!lazy) { // (the rank-boundary iterations do not use the cell side of the zones: k_cells works it out on demand)
         // prefix max of G_p and suffix min of H_p, side by side (one pair of barriers for both)
         int *wave_g = reinterpret_cast<int *>(wave_a);
@@ -2853,6 +2860,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     if (!lazy) for (int p = tid; p < ku; p += NT) { tab->gc[p] = gcell[p]; tab->hc[p] = hcell[p]; }
     if (tid == 0) { tab->n_ovf = 0; ws->cells_pending = (ONEWAVE || lazy) ? 0 : 1; ku_out[0] = ku; ku_out[1] = cur; }
     FSTAMP(7);
+    if (settled_event && ftr && tid == 0) ftr[26] = ftr[7];
 #undef FSTAMP
 #undef FIN_SYNC
 #undef FIN_OR
@@ -2967,7 +2975,11 @@ __global__ __launch_bounds__(KM_THREADS) void k_fit_small(const float *__restric
         src.zr = ws->bnd.zr; src.zl = ws->bnd.zl; src.cand = ws->bnd.cand; src.orig = ws->bnd.orig; src.ku = &ws->bnd.ku;
         bool published = false;
         int qn_seen = 0;
-        for (int j = wv; j < ku; j += KM_THREADS / 64) published |= km_bounds_wave<(KM_FUSE_KMAX + 63) / 64>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen);
+        for (int j = wv; j < ku; j += KM_THREADS / 64) {
+            KmBndPre<(KM_FUSE_KMAX + 63) / 64> pre;
+            km_bounds_preload<(KM_FUSE_KMAX + 63) / 64>(pre, j, lane, ws, src);
+            published |= km_bounds_wave<(KM_FUSE_KMAX + 63) / 64>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, pre);
+        }
         if (published || ws->help_hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
         // The sums went out as device-scope atomics (performed in L2); the first wave must not read them from a line its CU
         // still holds from the last round: drop the CU's cached copies (acquire), no write-back needed.
@@ -3354,7 +3366,9 @@ static int km_launch_lloyd(const float *xs, KmWs *w, const nnc_kmeans_params *p,
     if (p->k <= 128)
         NNC_LAUNCH_PROF(NNC_PROF_LLOYD, (k_lloyd<256>), dim3(1), dim3(256), lds, S(stream), xs, (long long)p->n, w, pb, budget_set, kc,
                         (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull, reloc);
-    else
+    else // (sixteen waves leave 128 registers a thread and the kernel spills some six hundred; eight waves -- 256 registers, 88 spilled --
+         // were measured slower all the same: K = 129: 1.04-1.19 of the launch-per-iteration time against 0.87-0.99, K = 257: 4.30 ms per
+         // bench step against 3.94: the searches want the waves more than the registers)
         NNC_LAUNCH_PROF(NNC_PROF_LLOYD, (k_lloyd<KM_THREADS>), dim3(1), dim3(KM_THREADS), lds, S(stream), xs, (long long)p->n, w, pb, budget_set, kc,
                         (nnc_kmeans_status *)nullptr, (unsigned long long *)nullptr, 0ull, reloc);
     LAUNCHCHK("k_lloyd");

@@ -20,9 +20,10 @@
 // iterations with more than a million undecided samples (two centres float32 can hardly tell apart) or a search that does not
 // settle (ws->wide: the k_bounds / k_finalize pair enqueued behind every launch of the loop runs exactly then).
 // Same integers, same float32 operations as the two-launch form: the trajectory is bit-identical (tests/test_gpu_lloyd.py).
-// Measured (tools/sweep_loop_vs_two.py, 0.1 M - 25 M weights): 0.46 - 0.8 of the launch-per-iteration time up to K = 65, about the
-// same at K = 129, 1.0 - 1.2 of it at K = 257 -- sixteen waves on one compute unit issue an instruction every eight cycles each, and
-// 512 searches of a few hundred instructions are then the bound -- so the library takes the loop up to NNC_KM_LOOP_KMAX centres.
+// Measured (tools/sweep_loop_vs_two.py, 0.1 M - 25 M weights; fit time against the launch-per-iteration form): 0.44 - 0.64 up to
+// K = 32, about the same at K = 65, 1.03 - 1.09 at K = 129, about 1.4 at K = 257 -- sixteen waves on one compute unit issue an
+// instruction every eight cycles each, and 512 searches of a few hundred instructions are then the bound -- so the library takes
+// the loop up to NNC_KM_LOOP_KMAX centres.
 //
 // Reference: the loop of sklearn/cluster/_kmeans.py:_kmeans_single_lloyd (624-752), reached from utility.py:237-238.
 
@@ -276,7 +277,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
             const float v = L.cnew[j];
             int rank = 0;
 #pragma unroll 8
-            for (int i = 0; i < k; i++) { const float u = L.cnew[i]; rank += (u < v) || (u == v && i < j); }
+            for (int i = 0; i < k; i++) { const float u = L.cnew[i]; rank += (int)(u < v) | ((int)(u == v) & (int)(i < j)); } // (no short circuit: no branches)
             L.call[rank] = v; L.perm[rank] = (uint16_t)j;
         }
         __syncthreads();
@@ -693,6 +694,7 @@ __device__ __forceinline__ void kl_label(const float *__restrict__ xs, const flo
 #define KL_RW 8      // candidates per end of a certain stretch: the lanes of a group
 #define KL_RM_MAX 7  // empty clusters one event may have here (KL_RM_MAX + 1 keys are selected)
 #define KL_RKPT 12   // candidate keys one thread holds during the selection
+#define KL_RPASS 10  // ends of certain stretches (groups of eight lanes) one thread takes: 2 ku <= KL_RPASS * NT / 8
 template <int NT>
 __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L,
                                            long long *sumo, long long *cnto, const int k, const int nch, const float mean, const int Sft)
@@ -700,19 +702,22 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = tid >> 3, gl = tid & 7;
     const int ku = hd->ku, m = hd->n_empty;
     if (tid == 0 && m > ws->kl_stats[7]) ws->kl_stats[7] = m; // (diagnostics: the largest event seen, why events were passed on)
-    if (m < 1 || m > KL_RM_MAX || 2 * ku > NT || hd->r_flat) { if (tid == 0) ws->kl_stats[6] |= 1; return 0; }
+    if (m < 1 || m > KL_RM_MAX || 2 * ku > KL_RPASS * (NT / 8) || hd->r_flat) { if (tid == 0) ws->kl_stats[6] |= 1; return 0; }
     unsigned long long *keys = ws->kl_keys;
     const int base = 2 * KL_RW * ku;
+    unsigned long long *rtr = NNC_FIN_TRACE_PTR; // diagnostics: phase stamps
+#define KRSTAMP(i) do { if (rtr && tid == 0) rtr[30 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    KRSTAMP(0);
     if (tid == 0) { hd->r_cnt = 0; hd->r_bad = 0; }
     __syncthreads();
     // ---- the ends of the certain stretches: group q = (centre p, lower / upper end), one sample a lane, the outermost first
     unsigned inner = 0u; // the largest distance of an innermost candidate that has samples behind it
-    {   // (2 ku <= NT: at most eight groups a thread; all their samples are fetched before any is looked at)
-        long long rr[8];
-        float xq[8];
-        bool deep[8];
+    {   // (at most KL_RPASS groups a thread; all their samples are fetched before any is looked at)
+        long long rr[KL_RPASS];
+        float xq[KL_RPASS];
+        bool deep[KL_RPASS];
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < KL_RPASS; u++) {
             const int q = g + u * (NT / 8);
             rr[u] = -1; deep[u] = false;
             if (q < 2 * ku) {
@@ -726,9 +731,9 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) xq[u] = rr[u] >= 0 ? xs[rr[u]] : 0.0f;
+        for (int u = 0; u < KL_RPASS; u++) xq[u] = rr[u] >= 0 ? xs[rr[u]] : 0.0f;
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < KL_RPASS; u++) {
             const int q = g + u * (NT / 8);
             if (q < 2 * ku) {
                 unsigned long long key = 0ull;
@@ -742,6 +747,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
             }
         }
     }
+    KRSTAMP(1); // certain ends
     // ---- the undecided stretches, chunk by chunk as kl_label went through them: exact label, then the distance to that centre
     const int *qfirst = reinterpret_cast<const int *>(L.call);
     for (int c = g; c < nch; c += NT / 8) {
@@ -752,29 +758,40 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
         const int cs_ = phi == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
         const long long start = s + (long long)cs_ * (c - qfirst[j]);
         const long long end = start + cs_ < e ? start + cs_ : e;
-        for (long long r = start + gl; r < end; r += 8) {
-            const float xv = xs[r];
-            const float xc = xv - mean;
-            float bestd = L.csq[j] + (-2.0f * (xc * L.cs[j]));
-            int best = j, besto = (int)L.so[j];
-            for (int cc = j + 1; cc <= phi; cc++) {
-                const float d = L.csq[cc] + (-2.0f * (xc * L.cs[cc]));
-                const int oc = (int)L.so[cc];
-                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = cc; besto = oc; }
+        for (long long r0 = start + gl; r0 < end; r0 += 64) { // eight loads a lane in flight
+            float xq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const long long r = r0 + 8 * u; xq[u] = r < end ? xs[r] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (r0 + 8 * u < end) {
+                    const float xv = xq[u];
+                    const float xc = xv - mean;
+                    float bestd = L.csq[j] + (-2.0f * (xc * L.cs[j]));
+                    int best = j, besto = (int)L.so[j];
+                    for (int cc = j + 1; cc <= phi; cc++) {
+                        const float d = L.csq[cc] + (-2.0f * (xc * L.cs[cc]));
+                        const int oc = (int)L.so[cc];
+                        if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = cc; besto = oc; }
+                    }
+                    const float dd = xc - L.cs[best];
+                    const float dv = dd * dd;
+                    const int slot = base + atomicAdd(&hd->r_cnt, 1);
+                    if (slot < KL_RKEYS) keys[slot] = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
+                }
             }
-            const float dd = xc - L.cs[best];
-            const float dv = dd * dd;
-            const int slot = base + atomicAdd(&hd->r_cnt, 1);
-            if (slot < KL_RKEYS) keys[slot] = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
         }
     }
+    KRSTAMP(2); // stretch samples (this wave)
     __syncthreads();
+    KRSTAMP(3);
     const int N = base + hd->r_cnt;
     if (N > KL_RKPT * NT || N > KL_RKEYS) { if (tid == 0) ws->kl_stats[6] |= 2; return 0; }
     // ---- the m + 1 largest keys: every thread holds its share in registers, one round of workgroup maximum per key
     unsigned long long kr[KL_RKPT];
 #pragma unroll
     for (int i = 0; i < KL_RKPT; i++) { const int slot = tid + i * NT; kr[i] = slot < N ? keys[slot] : 0ull; }
+    KRSTAMP(4); // keys back in registers
 #pragma unroll
     for (int r = 0; r <= KL_RM_MAX; r++) {
         if (r <= m) { // (the same on every thread)
@@ -806,6 +823,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
         } else if (tid == 0) hd->r_keys[r] = 0ull;
     }
     __syncthreads();
+    KRSTAMP(5); // rounds
     // ---- is the selection right, and is there anything to move?
     const unsigned long long kcut = hd->r_keys[m - 1], ktop = hd->r_keys[0];
     int bad = 0;
@@ -831,6 +849,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
             __syncthreads();
         }
     }
+    KRSTAMP(6); // proof vote + list of the empty clusters
     for (int i = wv; i < m; i += NT / 64) { // wave-uniform
         const float xv = f32_from_ordered_bits((unsigned)(hd->r_keys[i] & 0xFFFFFFFFull));
         const float xc = xv - mean;
@@ -884,6 +903,8 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
         }
     }
     __syncthreads();
+    KRSTAMP(7); // old clusters + edits
+#undef KRSTAMP
     return hd->r_bad ? 0 : 1;
 }
 

@@ -47,7 +47,7 @@ def test_missing_library_fails_loudly(monkeypatch):
 
 def test_struct_layouts():
     assert ctypes.sizeof(nat.KMeansParams) == 64
-    assert ctypes.sizeof(nat.KMeansStatus) == 48
+    assert ctypes.sizeof(nat.KMeansStatus) == 56   # (round 3: n_in_place + a reserved word; still a multiple of 8: the ticket behind it is aligned)
 
 
 def test_fix_shift_rule(lib):
