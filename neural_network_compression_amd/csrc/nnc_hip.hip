@@ -2429,7 +2429,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         // call that resumes behind a relocation (or finds it has nothing to do: the resume of a chain enqueued "in case") leaves
         // the queue and above all the announcement for the next pass alone (until round 3 the idle resume behind every iteration of
         // a batch with chains wiped it: the passes that most needed helpers at the queue went without)
-        const bool takes_a_pass = mode != FIN_FROM_PARTIALS || !resume;
+        const bool takes_a_pass = mode != FIN_FROM_PARTIALS; // (sharded: the packing call in front of the all-reduce has taken it)
         const int qn = takes_a_pass ? min(ws->q_n, (int)NNC_KMAX) : 0;
         for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
         if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
