@@ -518,7 +518,7 @@ int nnc_sort_pruned_bounded_flagged_(const float *x, int64_t n, int64_t n_neg, i
     if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     if (n_nz > 0) {
         const long long tiles = (n / 4 + 4 * SPLIT_THREADS - 1) / (4 * SPLIT_THREADS);
-        const int grid = (int)std::min<long long>(std::max<long long>(tiles, 1), 512);
+        const int grid = (int)std::min<long long>(std::max<long long>(tiles, 1), 512); // (one tile a workgroup, grid 2048, was measured: 324 us for the whole sorted copy against 315)
         hipLaunchKernelGGL(k_split_keys, dim3(grid), dim3(SPLIT_THREADS), 0, s, x, (long long)n, ka, counter, (long long)n_nz, bd);
         if ((e = hipGetLastError()) != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
         const int passes = (bits + RS_MAXBITS - 1) / RS_MAXBITS;
