@@ -390,7 +390,7 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         nnc_kmeans_status st;
         std::memset(&st, 0, sizeof(st));
         int32_t nwin = 0;
-        LCHK(nnc_kmeans_fit(xs, wb + L.km_ws, &p, 8, 1, L.reloc_bytes ? wb + L.reloc : nullptr, L.reloc_bytes, hb, ticket_io, &st, &nwin, stream));
+        LCHK(nnc_kmeans_fit(xs, wb + L.km_ws, &p, 16, 1, L.reloc_bytes ? wb + L.reloc : nullptr, L.reloc_bytes, hb, ticket_io, &st, &nwin, stream));
         if (!st.done) { // full-pass relocation / strict-convergence check: the caller's own path (from the pruned tensor)
             if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
             res->status = NNC_LAYER_HOST;

@@ -352,7 +352,7 @@ class DeviceKMeans:
     """One fit = one instance.  ``x`` float32, 1-D, contiguous, CUDA."""
 
     def __init__(self, x: torch.Tensor, init, group=None, max_iter: int = MAX_ITER, tol: float = TOL,
-                 batch: int = 8, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
+                 batch: int = 16, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
                  reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
                  n_total: int | None = None, n_min: int | None = None, comm=None, rank_boundaries: bool = True,
                  two_launch: bool = False, loop: bool = False):
