@@ -2630,7 +2630,9 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         FSTAMP(12);
         still_sorted = FIN_AND(2, ok);
         // nearly sorted (two neighbours changed places): a few odd-even transposition passes repair it
-        for (int pass = 0; pass < 3 && !still_sorted; pass++) {
+        // (not behind a relocation: a centre that was moved to a far sample is far from its old place, the passes would be for nothing)
+        const bool moved_far = resume || settled_event;
+        for (int pass = 0; pass < 3 && !still_sorted && !moved_far; pass++) {
             for (int parity = 0; parity < 2; parity++) {
                 for (int p = 2 * tid + parity; p + 1 < k; p += 2 * NT) {
                     const float va = cs[p], vb = cs[p + 1];

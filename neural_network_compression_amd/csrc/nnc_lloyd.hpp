@@ -792,9 +792,10 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
 #pragma unroll
     for (int i = 0; i < KL_RKPT; i++) { const int slot = tid + i * NT; kr[i] = slot < N ? keys[slot] : 0ull; }
     KRSTAMP(4); // keys back in registers
-#pragma unroll
-    for (int r = 0; r <= KL_RM_MAX; r++) {
-        if (r <= m) { // (the same on every thread)
+    if (tid <= KL_RM_MAX) hd->r_keys[tid] = 0ull;
+#pragma unroll 1
+    for (int r = 0; r <= m; r++) { // (one copy of the round's code, not eight: it runs once or twice a call and every copy arrives cold)
+        {
             unsigned long long bk = 0ull;
             int bi = -1;
 #pragma unroll
@@ -820,7 +821,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
 #pragma unroll
                 for (int i = 0; i < KL_RKPT; i++) if (i == mine) kr[i] = 0ull;
             }
-        } else if (tid == 0) hd->r_keys[r] = 0ull;
+        }
     }
     __syncthreads();
     KRSTAMP(5); // rounds
