@@ -758,6 +758,10 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
         const int cs_ = phi == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
         const long long start = s + (long long)cs_ * (c - qfirst[j]);
         const long long end = start + cs_ < e ? start + cs_ : e;
+        // (one slot range a chunk: a counter bumped once per SAMPLE -- six thousand LDS atomics on one word -- was most of this phase)
+        int cbase = 0;
+        if (gl == 0) cbase = atomicAdd(&hd->r_cnt, (int)(end - start));
+        cbase = __shfl(cbase, (int)(threadIdx.x & 63 & ~7));
         for (long long r0 = start + gl; r0 < end; r0 += 64) { // eight loads a lane in flight
             float xq[8];
 #pragma unroll
@@ -776,7 +780,7 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
                     }
                     const float dd = xc - L.cs[best];
                     const float dv = dd * dd;
-                    const int slot = base + atomicAdd(&hd->r_cnt, 1);
+                    const int slot = base + cbase + (int)(r0 + 8 * u - start);
                     if (slot < KL_RKEYS) keys[slot] = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
                 }
             }
