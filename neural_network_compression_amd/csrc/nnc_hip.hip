@@ -2006,9 +2006,10 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
                 }
             }
         }
-        // (an announced pass: the others wait at the queue until every wave has said whether it had something to publish;
-        // release: the record above is out before the count)
-        if (announced && lane == 0) __hip_atomic_fetch_add(&ws->q_searched, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        // (an announced pass: the others wait at the queue until every wave has said whether it had something to publish.
+        // Relaxed: a release at agent scope writes this XCD's L2 back -- measured 8 us a wave; the record above went out as atomic
+        // stores in front of this one, and a helper that should still miss it costs nothing but its help)
+        if (announced && lane == 0) __hip_atomic_fetch_add(&ws->q_searched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         float uv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (quick) {
 #pragma unroll
@@ -2131,9 +2132,7 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     // until every wave of the pass is through its searches (q_searched: whatever there was to publish is out by then).  Nobody's
     // PROGRESS depends on this -- a publisher sees its own tiles through alone if need be -- and the number of looks is bounded,
     // so the loop ends whatever the others do.  Cost: the pass lasts as long as its slowest search plus one look (+ 4 us).
-    // (One wave of every workgroup waits and helps, the others leave: 260 waves polling one word cost each announced pass 9 us.)
     const bool waits = hint == 2 && !published && fixed_src;
-    if (waits && (threadIdx.x >> 6) != 0 && uni_i(qn_seen) == 0) return;
     if (waits) {
         const int nwaves = pre.ku;
         for (int look = 0; look < 128; look++) {
