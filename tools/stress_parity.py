@@ -9,6 +9,7 @@ from oracle import oracle as orc
 
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+form = sys.argv[3] if len(sys.argv) > 3 else "auto"   # auto: the library's choice; loop / two: the resident loop / the launch-per-iteration pair at any K
 bad = 0
 t0 = time.time()
 for case in range(ncases):
@@ -36,7 +37,7 @@ for case in range(ncases):
     if init.size < k:
         init = np.concatenate([init, np.full(k - init.size, init[-1], dtype=np.float32)])
     ob = orc.kmeans_lloyd(x, init, accum="B")
-    km = kmeans.DeviceKMeans(torch.from_numpy(x).cuda(), init)
+    km = kmeans.DeviceKMeans(torch.from_numpy(x).cuda(), init, loop=form == "loop", two_launch=form == "two")
     model, vals = km.fit()
     ok = (model.n_iter_ == ob.n_iter_ and np.array_equal(model.cluster_centers_.ravel(), ob.cluster_centers_.ravel())
           and np.array_equal(model.labels_, ob.labels_)
@@ -44,5 +45,5 @@ for case in range(ncases):
     print(f"case {case}: n={n} k={k} kind={kind} init={style} n_iter={model.n_iter_}/{ob.n_iter_} reloc={model.n_relocations_} "
           f"windowed={model.n_reloc_windowed_} stop={model.stop_reason_} {'ok' if ok else 'MISMATCH'}", flush=True)
     bad += (not ok)
-print(f"{ncases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
+print(f"seed {sys.argv[1] if len(sys.argv) > 1 else 1}, form {form}: {ncases} cases, {bad} mismatches, {time.time() - t0:.0f} s")
 sys.exit(1 if bad else 0)
