@@ -206,7 +206,8 @@ typedef struct nnc_kmeans_params {
 #define NNC_KM_TWO_LAUNCH 1
 /* ... and the other way round: the one-workgroup loop whatever the number of centres (by itself the library takes it up to
  * NNC_KM_LOOP_KMAX centres, where one compute unit's instruction rate is not yet the bound: measured on 0.1 M - 25 M weights it
- * takes 0.46 - 0.8 of the launch-per-iteration time up to K = 65, about the same at K = 129, 1.0 - 1.2 of it at K = 257). */
+ * takes 0.44 - 0.64 of the launch-per-iteration time up to K = 32, about the same at K = 65, 1.03 - 1.09 of it at K = 129 and about
+ * 1.4 at K = 257). */
 #define NNC_KM_LOOP 2
 #define NNC_KM_LOOP_KMAX 64
 
