@@ -2290,6 +2290,8 @@ __device__ __forceinline__ KmZone km_pair_zone(const double cp, const double cq,
 // how far the crossing point of a pair can lie from its midpoint at most (for the early exit of the loops over the pairs)
 __device__ __forceinline__ double km_pair_slack(const double delta, const double xb) { return 1.25e-7 * xb * xb * km_rcp_up(delta); }
 
+// workgroup barrier that orders LDS traffic only (see km_finalize_body)
+__device__ __forceinline__ void km_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned f32_ordered_bits(float x)
 {
     const unsigned u = __float_as_uint(x);
@@ -2302,8 +2304,6 @@ __device__ __forceinline__ float f32_from_ordered_bits(unsigned o)
 
 #include "nnc_lloyd.hpp"
 
-// workgroup barrier that orders LDS traffic only (see km_finalize_body)
-__device__ __forceinline__ void km_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory"); }
 // workgroup votes through an LDS word that starts at zero and is used once per launch
 __device__ __forceinline__ int km_vote_or(int *word, const int x)
 {

@@ -1011,7 +1011,8 @@ __device__ __forceinline__ int kl_finish(const float *__restrict__ xs, KmWs *__r
 
 // ---- the same step when nothing unusual happens: every centre distinct (one thread per cluster, k <= NT), no empty cluster, the
 // order of the centres unchanged.  Then nothing has to change places: thread p owns the p-th centre in value order from the sums
-// to the zones, and the step needs seven workgroup barriers instead of some forty.  Returns -1 (before it has changed anything
+// to the zones, and the step needs seven workgroup barriers instead of some forty -- barriers that order the LDS traffic only
+// (km_lds_barrier): a __syncthreads() would also wait for the global stores of the step (state for the other kernels, write-only here).  Returns -1 (before it has changed anything
 // that the general step would not change in the same way) when that does not hold; else 0 = go on, 1 = stopped, 2 = paused.
 template <int NT>
 __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, const long long n, const long long total,
@@ -1049,7 +1050,7 @@ __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs
     }
     if (__any(empty) && lane == 0) hd->f_empty = 1;
     if (__any(diff) && lane == 0) hd->f_diff = 1;
-    __syncthreads();                                                                                   // ---- 1
+    km_lds_barrier();                                                                                   // ---- 1
     KLSTAMP(5);
     const int any_empty = hd->f_empty, any_diff = hd->f_diff;
     if (tid == 0) ws->st.same_counts = any_diff ? 0 : 1;
@@ -1085,7 +1086,7 @@ __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs
     if (mine && p + 1 < k) ok = cn < L.cnew[L.so[p + 1]]; // strictly: equal centres would have to be merged
     if (!__all(ok) && lane == 0) hd->f_reorder = 1;
 
-    __syncthreads();                                                                                   // ---- 2
+    km_lds_barrier();                                                                                   // ---- 2
     KLSTAMP(6);
     if (tid < 64 && k > LEAF) {
         for (int lev = hd->depth - 1; lev >= 0; lev--) {
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs
         ws->bnd.cand[p] = make_float2(cn, v2); ws->bnd.orig[p] = (uint16_t)o;
     }
     if (tid == 0) { tab->ku = k; ws->ku_cur = k; ws->bnd.ku = k; tab->n_ovf = 0; ws->cells_pending = 0; hd->f_diff = 0; }
-    __syncthreads();                                                                                   // ---- 3
+    km_lds_barrier();                                                                                   // ---- 3
     KLSTAMP(7);
     const float tot = hd->tot;
     int done = 0;
@@ -1138,7 +1139,7 @@ __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs
         const KmZone z = km_pair_zone((double)cn, (double)L.cs[p + 1], xb);
         L.Ub[p] = z.hi; L.Lb[p + 1] = z.lo;
     }
-    __syncthreads();
+    km_lds_barrier();
     if (mine) {
         const double cp = (double)cn;
         if (p + 1 < k) right = L.Ub[p];
@@ -1169,7 +1170,7 @@ __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs
     }
     if (lane == 63) hd->wmax[wv] = um;
     if (lane == 0) hd->wmin[wv] = sn;
-    __syncthreads();                                                                                   // ---- 4
+    km_lds_barrier();                                                                                   // ---- 4
     KLSTAMP(10);
     for (int w = 0; w < NT / 64; w++) {
         if (w < wv) um = fmax(um, hd->wmax[w]);
@@ -1190,13 +1191,13 @@ __device__ __forceinline__ int kl_finish_fast(const float *__restrict__ xs, KmWs
         if (p == k - 1) { L.Lb[p] = INFINITY; L.Lf[p] = INFINITY; }
     }
     if (tid == 0) hd->ku = k;
-    __syncthreads();                                                                                   // ---- 5
+    km_lds_barrier();                                                                                   // ---- 5
     if (mine && p + 1 < k) { // phi_p: the highest centre that can still win below U_p
         int q = p + 1;
         while (q + 1 < k && L.Lb[q] <= um) q++;
         L.phi[p] = (uint16_t)q;
     }
-    __syncthreads();                                                                                   // ---- 6
+    km_lds_barrier();                                                                                   // ---- 6
     KLSTAMP(11);
     return done ? 1 : 0;
 }
