@@ -169,7 +169,7 @@ __device__ __forceinline__ void kl_pairwise(KlHead *hd, const float *e, int n) /
             const int l = hp->len[node];
             if (l > 0 && l <= LEAF) { const float r = kl_leaf_sum(e, hp->start[node], l, j8); if (j8 == 0) hp->val[node] = r; }
         }
-        __syncthreads();
+        km_lds_barrier();
         if (tid < 64) {
             for (int lev = depth - 1; lev >= 0; lev--) {
                 const int i = (1 << lev) + lane;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void kl_pairwise(KlHead *hd, const float *e, int n) /
             if (lane == 0) hd->tot = hp->val[1];
         }
     }
-    __syncthreads();
+    km_lds_barrier();
 }
 
 // ---- zone ends per centre (zl in Lb[], zr in Ub[]) -> thresholds per boundary, and whether any three centres crowd --------------
@@ -203,22 +203,22 @@ __device__ __forceinline__ void kl_derive(KlHead *hd, const KlArr &L, int ku)
                 a[r] = (q < ku && q >= off) ? fmax(L.Ub[q], L.Ub[q - off]) : (q < ku ? L.Ub[q] : 0.0);
                 b[r] = (q < ku && q + off < ku) ? fmin(L.Lb[q], L.Lb[q + off]) : (q < ku ? L.Lb[q] : 0.0);
             }
-            __syncthreads();
+            km_lds_barrier();
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int q = tid + r * NT;
                 if (q < ku) { L.Ub[q] = a[r]; L.Lb[q] = b[r]; }
             }
-            __syncthreads();
+            km_lds_barrier();
         }
     }
     double t[2];
 #pragma unroll
     for (int r = 0; r < 2; r++) { const int q = tid + r * NT; t[r] = (q + 1 < ku) ? L.Lb[q + 1] : INFINITY; }
-    __syncthreads();
+    km_lds_barrier();
 #pragma unroll
     for (int r = 0; r < 2; r++) { const int q = tid + r * NT; if (q < ku) L.Lb[q] = t[r]; }
-    __syncthreads();
+    km_lds_barrier();
     // phi_j = max{q : zl[q] <= U_j}: the candidates of the samples boundary j cannot decide from the zones are the centres j .. phi_j
     // (j + 1 unless centres crowd).  With the running minimum in place: the largest q whose L_{q-1} is still <= U_j.
     for (int j = tid; j + 1 < ku; j += NT) {
@@ -232,7 +232,7 @@ __device__ __forceinline__ void kl_derive(KlHead *hd, const KlArr &L, int ku)
         if ((double)uf > u) uf = nextafterf(uf, -INFINITY);
         L.Lf[j] = lf; L.Uf[j] = uf;
     }
-    __syncthreads();
+    km_lds_barrier();
 }
 
 // ---- order of the centres, distinct values, zones: what km_finalize_body leaves for the next E-step, from cnew[] in LDS --------
@@ -246,7 +246,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
     int still_sorted = 0;
     if (!fresh) {
         for (int p = tid; p < k; p += NT) L.call[p] = L.cnew[L.perm[p]];
-        __syncthreads();
+        km_lds_barrier();
         int ok = 1;
         for (int p = tid; p + 1 < k; p += NT) {
             const float va = L.call[p], vb = L.call[p + 1];
@@ -262,7 +262,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
                     const uint16_t a = L.perm[p], b = L.perm[p + 1];
                     if (!((va < vb) || (va == vb && a < b))) { L.call[p] = vb; L.call[p + 1] = va; L.perm[p] = b; L.perm[p + 1] = a; }
                 }
-                __syncthreads();
+                km_lds_barrier();
             }
             int ok2 = 1;
             for (int p = tid; p + 1 < k; p += NT) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
             for (int i = 0; i < k; i++) { const float u = L.cnew[i]; rank += (int)(u < v) | ((int)(u == v) & (int)(i < j)); } // (no short circuit: no branches)
             L.call[rank] = v; L.perm[rank] = (uint16_t)j;
         }
-        __syncthreads();
+        km_lds_barrier();
     }
     KLSTAMP(8); // order
     // equal centres: the first one (lowest original index) takes every tie, the others never win: distinct values only
@@ -300,12 +300,12 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
             const unsigned long long bal = __ballot(first);
             const int before = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
             if ((tid & 63) == 0) hd->wave_i[tid >> 6] = __popcll(bal);
-            __syncthreads();
+            km_lds_barrier();
             int pre = carry, tot = carry;
             for (int w = 0; w < NT / 64; w++) { const int wv = hd->wave_i[w]; if (w < (tid >> 6)) pre += wv; tot += wv; }
             if (first) { L.cs[pre + before] = v; L.so[pre + before] = (uint16_t)o; }
             carry = tot;
-            __syncthreads();
+            km_lds_barrier();
         }
         ku = carry;
     }
@@ -326,7 +326,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
         const KmZone z = km_pair_zone((double)L.cs[p], (double)L.cs[p + 1], xb);
         L.Ub[p] = z.hi; L.Lb[p + 1] = z.lo;
     }
-    __syncthreads();
+    km_lds_barrier();
     for (int p = tid; p < ku; p += NT) {
         const double cp = (double)L.cs[p];
         double right = p + 1 < ku ? L.Ub[p] : INFINITY, left = p > 0 ? L.Lb[p] : -INFINITY;
@@ -348,7 +348,7 @@ __device__ __forceinline__ void kl_tables(KmWs *__restrict__ ws, KlHead *hd, con
         tab->zl[p] = left; tab->zr[p] = right;
         ws->bnd.zl[p] = left; ws->bnd.zr[p] = right;
     }
-    __syncthreads();
+    km_lds_barrier();
     KLSTAMP(10); // zones
     kl_derive<NT>(hd, L, ku);
     KLSTAMP(11); // thresholds, candidate ranges
@@ -930,7 +930,7 @@ __device__ __forceinline__ int kl_finish_tail(KmWs *__restrict__ ws, KlHead *hd,
         const float sft = (float)sqrt((double)s2);
         L.sq[j] = sft * sft;
     }
-    __syncthreads();
+    km_lds_barrier();
     kl_pairwise<NT>(hd, L.sq, k);
     const float tot = hd->tot;
     iter += 1;
@@ -944,7 +944,7 @@ __device__ __forceinline__ int kl_finish_tail(KmWs *__restrict__ ws, KlHead *hd,
         ws->cur = cur;
     }
     for (int j = tid; j < k; j += NT) { const float c = L.cnew[j]; ws->c[cur][j] = c; L.cold[j] = c; }
-    __syncthreads();
+    km_lds_barrier();
     KLSTAMP(7); // shift, pairwise sum, state
     kl_tables<NT>(ws, hd, L, k, cur, false, p_lo, p_hi, dg);
     return done ? 1 : 0;
