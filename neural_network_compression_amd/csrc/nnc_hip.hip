@@ -2536,7 +2536,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         settled_event = false;
         if constexpr (!ONEWAVE) {
             // (the same conditions under which the chain enqueued "in case" goes ahead: km_spec_decide)
-            if (n_empty > 0 && !resume && reloc_xs && mode == FIN_FROM_SHARDS && lazy && !(st_iter >= 1 && same_counts_now)) {
+            // (n_empty counts THREADS with an empty cluster here: more of them than the selection takes clusters is a mass event)
+            if (n_empty > 0 && n_empty <= KL_RM_MAX && !resume && reloc_xs && mode == FIN_FROM_SHARDS && lazy && !(st_iter >= 1 && same_counts_now)) {
                 __syncthreads(); // (the global stores of this step so far are out before the selection reads the workspace)
                 if (ftr && tid == 0) { ftr[20] = ftr[0]; ftr[21] = __builtin_amdgcn_s_memrealtime(); }
                 const KmTab *tabc = &ws->tab[cur];
