@@ -893,7 +893,7 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 // integer addition makes the result independent of any ordering.
 //
 #define KM_THREADS 1024
-#define KL_RKEYS 12288 // candidate keys an empty-cluster event inside the one-workgroup loop may have (12 per thread)
+#define KL_RKEYS 16384 // candidate keys an empty-cluster event inside the one-workgroup loop may have (16 per thread)
 #define KM_NSHARD 8
 #define KM_GMAX 32768
 #define KM_CNT_SAT 31
@@ -2373,7 +2373,7 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
         if (len > 0) {
             const int cs_ = (int)L.phi[j] == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
             const long long nc = (len + cs_ - 1) / cs_;
-            if (nc > 16) hd->slow = 1;
+            if (nc > 64) hd->slow = 1;
             else {
                 const int first = atomicAdd(&hd->nch, (int)nc);
                 qfirst[j] = first;
@@ -2382,7 +2382,7 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
         }
     }
     __syncthreads();
-    if (hd->slow || hd->nch > 256) return 0;
+    if (hd->slow || hd->nch > 1024) return 0; // (beyond that the candidate list would not fit anyway: kl_relocate checks)
     return kl_relocate<NT>(xs, n, ws, hd, L, sum_o, cnt_o, k, hd->nch, mean, Sft);
 }
 

@@ -693,7 +693,7 @@ __device__ __forceinline__ void kl_label(const float *__restrict__ xs, const flo
 // has changed then and the caller pauses as before -- the relocation chain behind the launch, or the host, takes the event.
 #define KL_RW 8      // candidates per end of a certain stretch: the lanes of a group
 #define KL_RM_MAX 7  // empty clusters one event may have here (KL_RM_MAX + 1 keys are selected)
-#define KL_RKPT 12   // candidate keys one thread holds during the selection
+#define KL_RKPT 16   // candidate keys one thread holds during the selection
 #define KL_RPASS 10  // ends of certain stretches (groups of eight lanes) one thread takes: 2 ku <= KL_RPASS * NT / 8
 template <int NT>
 __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L,
