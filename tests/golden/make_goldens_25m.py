@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Golden record of BASELINE configs[3] at its FULL size, made by the reference itself.
+
+    python tests/golden/make_goldens_25m.py ref      # the reference's own functions, one thread        (~15 min)
+    python tests/golden/make_goldens_25m.py oracleB  # oracle, accumulation mode B (what the device runs) (~5 min)
+    python tests/golden/make_goldens_25m.py oracleA  # oracle, mode A + numpy.argpartition (== reference) (~5 min)
+    python tests/golden/make_goldens_25m.py merge    # -> tests/golden/ref_goldens_25m.json
+
+Runs ONLY in the build container (needs /root/reference).  Input = bench.py's input: synth seed 4000, 25 000 000 float32
+weights.  Pipeline = bench.py's step = what Trainer.quantize does to one tensor after pruning:
+
+    prune_weigth(w, 1, True)                     /root/reference/neural_network_compression/common/utility.py:134-163
+    get_weight_distribution(non-zero weights)    utility.py:334-392  (zero strip: common/trainer.py:55-59)
+    get_quantized_weight(w, 8, "density", cdfs)  utility.py:172-240  (K = 2^8 + 1 = 257, utility.py:212)
+
+The vectors themselves (100 MB each) are not committed: the record holds the 257 centres and the initial centres by their
+bits, n_iter_, the index histogram, SHA-256 of the mask / index vector / decoded tensor, sigma, and -- computed here, where
+both index vectors exist -- how many indices differ between the reference and mode B.  Same two harness-side adaptations as
+make_goldens.py (algorithm="full" is spelled "lloyd" in scikit-learn 1.7.2; threadpool_limits(1)).
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+import time
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+import numpy as np  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from neural_network_compression_amd import synth  # noqa: E402
+
+N, SEED, Q, BITS, MODE = 25_000_000, 4000, 1, 8, "density"
+SCRATCH = os.environ.get("NNC_GOLDEN_SCRATCH", "/tmp/nnc_golden_25m")
+OUT = os.path.join(HERE, "ref_goldens_25m.json")
+
+
+def sha(a) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits32(a):
+    return [int(v) for v in np.ascontiguousarray(a, dtype=np.float32).ravel().view(np.uint32)]
+
+
+def bits64(a):
+    return [int(v) for v in np.ascontiguousarray(a, dtype=np.float64).ravel().view(np.uint64)]
+
+
+def record(km, q, init, extra=None):
+    centers = km.cluster_centers_.ravel()
+    labels = np.asarray(km.labels_)
+    r = {
+        "K": int(centers.size), "n_iter": int(km.n_iter_),
+        "init_bits": bits32(init), "centers_bits": bits32(centers), "centers_dtype": str(centers.dtype),
+        "labels_dtype": str(labels.dtype), "labels_sha256_int32": sha(labels.astype(np.int32)),
+        "bincount": [int(v) for v in np.bincount(labels, minlength=centers.size)],
+        "quantized_sha256": sha(q), "quantized_dtype": str(q.dtype),
+    }
+    r.update(extra or {})
+    return r, labels.astype(np.uint16)
+
+
+def stage_ref():
+    import importlib.util
+
+    import sklearn
+    import sklearn.cluster
+    from threadpoolctl import threadpool_limits
+
+    spec = importlib.util.spec_from_file_location("ref_utility", "/root/reference/neural_network_compression/common/utility.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    captured = {}
+
+    def kmeans_factory(*args, **kwargs):
+        if kwargs.get("algorithm") in ("full", "auto"):
+            kwargs["algorithm"] = "lloyd"
+        captured["init"] = np.array(kwargs["init"], copy=True)
+        return sklearn.cluster.KMeans(*args, **kwargs)
+
+    ref.KMeans = kmeans_factory
+    t0 = time.time()
+    w = synth.weights((N,), SEED)
+    out = {"n": N, "seed": SEED, "q": Q, "bits": BITS, "mode": MODE, "input_sha256": sha(w),
+           "versions": {"numpy": np.__version__, "sklearn": sklearn.__version__}}
+    with threadpool_limits(1):
+        sigma = np.std(w)
+        mask = ref.prune_weigth(w, threshold=Q, std_smooth=True)
+        out.update({"sigma_bits": bits32(sigma)[0], "nzeroed": int(mask.sum()), "mask_sha256": sha(np.packbits(mask)),
+                    "pruned_sha256": sha(w)})
+        flat = w.flatten()
+        nz = np.delete(flat, np.nonzero(flat == 0)[0], axis=0)   # trainer.py:55-59
+        xnew, cdf = ref.get_weight_distribution(nz)
+        out.update({"xnew_bits": bits32(xnew), "cdf_bits": bits64(cdf), "n_nonzero": int(nz.size)})
+        print(f"[ref] prune + CDF done at {time.time() - t0:.0f} s; fitting ...", flush=True)
+        q, km = ref.get_quantized_weight(w.copy(), bits=BITS, mode=MODE, cdfs=(xnew, cdf))
+    rec, lab = record(km, q, captured["init"].ravel().astype(np.float32), {"seconds_one_thread": round(time.time() - t0, 1)})
+    out["reference"] = rec
+    np.save(os.path.join(SCRATCH, "labels_ref.npy"), lab)
+    json.dump(out, open(os.path.join(SCRATCH, "ref.json"), "w"))
+    print(f"[ref] n_iter={km.n_iter_} in {time.time() - t0:.0f} s", flush=True)
+
+
+def stage_oracle(accum):
+    from oracle import oracle as orc
+
+    t0 = time.time()
+    w = synth.weights((N,), SEED)
+    orc.prune_weigth(w, Q, True)
+    flat = w.ravel()
+    cdfs = orc.get_weight_distribution(flat[flat != 0])
+    init = orc.init_space(w, BITS, MODE, cdfs)
+    km = orc.kmeans_lloyd(flat, init, accum=accum, reloc="argpartition" if accum == "A" else "descending")
+    q = km.cluster_centers_[km.labels_].reshape(w.shape)
+    rec, lab = record(km, q, np.asarray(init, dtype=np.float32), {
+        "accum": accum, "strict": bool(km.strict), "tol_bits": bits32(km.tol_)[0], "x_mean_bits": bits32(km.x_mean_)[0],
+        "fix_shift": int(km.fix_shift_), "reloc_info": {k: int(v) for k, v in km.reloc_info_.items()},
+        "pruned_sha256": sha(w), "seconds": round(time.time() - t0, 1)})
+    np.save(os.path.join(SCRATCH, f"labels_oracle{accum}.npy"), lab)
+    json.dump(rec, open(os.path.join(SCRATCH, f"oracle{accum}.json"), "w"))
+    print(f"[oracle {accum}] n_iter={km.n_iter_} in {time.time() - t0:.0f} s", flush=True)
+
+
+def stage_merge():
+    out = json.load(open(os.path.join(SCRATCH, "ref.json")))
+    lref = np.load(os.path.join(SCRATCH, "labels_ref.npy"))
+    cref = np.array(out["reference"]["centers_bits"], dtype=np.uint32).view(np.float32).astype(np.float64)
+    for accum in ("B", "A"):
+        p = os.path.join(SCRATCH, f"oracle{accum}.json")
+        if not os.path.exists(p):
+            continue
+        rec = json.load(open(p))
+        lab = np.load(os.path.join(SCRATCH, f"labels_oracle{accum}.npy"))
+        c = np.array(rec["centers_bits"], dtype=np.uint32).view(np.float32).astype(np.float64)
+        rec["vs_reference"] = {
+            "labels_differing": int(np.count_nonzero(lab != lref)),
+            "hist_l1": int(np.abs(np.array(rec["bincount"]) - np.array(out["reference"]["bincount"])).sum()),
+            "max_rel_centre_err": float(np.max(np.abs(c - cref) / np.maximum(np.abs(cref), 1e-30))),
+            "max_abs_centre_err": float(np.max(np.abs(c - cref))),
+            "centres_differing": int(np.count_nonzero(c != cref)),
+            "n_iter_equal": rec["n_iter"] == out["reference"]["n_iter"],
+        }
+        out[f"oracle_{accum}"] = rec
+    json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
+    print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    os.makedirs(SCRATCH, exist_ok=True)
+    {"ref": stage_ref, "oracleB": lambda: stage_oracle("B"), "oracleA": lambda: stage_oracle("A"), "merge": stage_merge}[sys.argv[1]]()
