@@ -301,15 +301,12 @@ def _worker_stream(dev) -> torch.cuda.Stream:
         st[dev] = torch.cuda.Stream(device=dev)
     return st[dev]
 
-
-def compress_layers(layers, workers: int = 8, **kw):
+def _compress_layers_local(layers, workers: int = 8, **kw):
     """compress_layer for every tensor of ``layers`` (device float32 tensors, each pruned in place when ``q`` is given),
     ``workers`` of them side by side on streams of their own; the results come back in the order of ``layers`` and are the ones
     the calls would give one after the other.  Modes that draw from NumPy's global generator (forgy) run one after the other,
     so that the draws stay in layer order like the reference's.  ``kw``: the arguments of compress_layer (single GPU)."""
     layers = list(layers)
-    if kw.get("group") is not None:
-        raise ValueError("compress_layers works on whole tensors of one GPU")
     if workers <= 1 or len(layers) <= 1 or kw.get("mode", "linear") == "forgy":
         return [compress_layer(t, **kw) for t in layers]
     dev = layers[0].device
@@ -344,3 +341,131 @@ def compress_layers(layers, workers: int = 8, **kw):
             if isinstance(t, torch.Tensor) and t.is_cuda:
                 t.record_stream(main)
     return results
+
+
+# ------------------------------------------------------------------ the layers of a model over the GPUs of a node
+@dataclass
+class LayerRecord:
+    """What every rank knows about every layer after compress_layers(group=...): the K-sized results (a few hundred bytes a
+    layer; the index and value vectors stay on the rank that made them, in ``result``)."""
+    index: int
+    n: int
+    rank: int                       # owner, or -1: sharded over all ranks of the group
+    nzeroed: int | None
+    sigma: float | None
+    threshold: float | None
+    centers: np.ndarray | None      # float32[K], None if the tensor passed through ("not enough bits")
+    counts: np.ndarray | None
+    code_lengths: np.ndarray | None
+    total_bits: int | None
+    n_iter: int
+    n_relocations: int
+    stop: str | None
+    result: LayerResult | None = None   # this rank's LayerResult (owner, or this rank's shard); None on the other ranks
+
+
+def layer_cost(n: int) -> float:
+    """Seconds one GPU spends on a tensor of n weights, to the accuracy a schedule needs: a fit is a chain of short dependent
+    launches whatever the length (some 0.35 ms for the 4-bit fits of BASELINE configs[4]), the passes over the vector add
+    about 0.1 ns a weight."""
+    return 0.35e-3 + 1.0e-10 * int(n)
+
+
+def partition_layers(sizes, world: int, shard_above: int | None = None, cost=layer_cost):
+    """owner[i] for every tensor: longest processing time first onto the least loaded rank (ties: the lowest rank, the lowest
+    index first -- every rank computes the same table from the sizes alone); -1 for tensors of ``shard_above`` weights or
+    more, which all ranks work on together as shards."""
+    sizes = [int(s) for s in sizes]
+    owner = [0] * len(sizes)
+    load = [0.0] * world
+    for i in sorted(range(len(sizes)), key=lambda i: (-cost(sizes[i]), i)):
+        if shard_above is not None and sizes[i] >= shard_above and world > 1:
+            owner[i] = -1
+            continue
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[i] = r
+        load[r] += cost(sizes[i])
+    return owner
+
+
+def _record(i, n, rank, r: LayerResult) -> LayerRecord:
+    m = r.model
+    return LayerRecord(i, int(n), rank, r.nzeroed, r.sigma, r.threshold,
+                       None if m is None else np.asarray(m.cluster_centers_, dtype=np.float32).ravel().copy(),
+                       r.counts, r.code_lengths, r.total_bits, 0 if m is None else int(m.n_iter_),
+                       0 if m is None else int(m.n_relocations_), None if m is None else m.stop_reason_, r)
+
+
+def _compress_layers_ranks(layers, sizes, workers, group, shard_above, comm, _compress, kw):
+    import copy
+
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if kw.get("mode", "linear") in ("forgy", "kmeans++"):
+        raise ValueError("compress_layers(group=...): modes that draw from NumPy's global generator (forgy, kmeans++) consume it in layer "
+                         "order (common/trainer.py:50-70) and cannot be dealt out to ranks; run them on one rank")
+    if sizes is None:
+        if any(t is None for t in layers):
+            raise ValueError("compress_layers(group=...): `sizes` (the length of EVERY tensor, the same list on every rank) is needed "
+                             "when this rank holds only its own tensors")
+        sizes = [t.numel() for t in layers]
+    if len(sizes) != len(layers):
+        raise ValueError(f"compress_layers: {len(layers)} layers but {len(sizes)} sizes")
+    owner = partition_layers(sizes, world, shard_above)
+    records = {}
+    # tensors every rank holds a shard of: all ranks together, one after the other in index order (each is a chain of collectives)
+    for i in [i for i, o in enumerate(owner) if o < 0]:
+        if layers[i] is None:
+            raise ValueError(f"compress_layers: tensor {i} ({sizes[i]} weights) is sharded over the group; this rank's shard is missing")
+        r = _compress(layers[i], group=group, comm=comm, **kw)
+        records[i] = _record(i, sizes[i], -1, r)
+    mine = [i for i, o in enumerate(owner) if o == rank]
+    for i in mine:
+        if layers[i] is None or layers[i].numel() != sizes[i]:
+            raise ValueError(f"compress_layers: tensor {i} belongs to rank {rank} (partition_layers) and must be given whole "
+                             f"({sizes[i]} weights)")
+    if _compress is compress_layer:
+        res = _compress_layers_local([layers[i] for i in mine], workers=workers, **kw)
+    else:
+        res = [_compress(layers[i], **kw) for i in mine]
+    for i, r in zip(mine, res):
+        records[i] = _record(i, sizes[i], rank, r)
+    # every rank learns every layer's K-sized results: one object gather (a few hundred bytes a layer, no data-path collective)
+    wire = []
+    for i in mine:
+        c = copy.copy(records[i])
+        c.result = None
+        wire.append(c)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, wire, group=group)
+    for part in gathered:
+        for rec in part:
+            if rec.index not in records:
+                records[rec.index] = rec
+    missing = [i for i in range(len(sizes)) if i not in records]
+    if missing:
+        raise RuntimeError(f"compress_layers: no rank reported tensors {missing[:8]}")
+    return [records[i] for i in range(len(sizes))]
+
+
+def compress_layers(layers, workers: int = 8, group=None, sizes=None, shard_above: int | None = None, comm=None, _compress=None, **kw):
+    """compress_layer for every tensor of a model (Trainer.quantize's loop, common/trainer.py:50-70).
+
+    One GPU (``group=None``): ``workers`` tensors side by side on streams of their own (see _compress_layers_local); returns the
+    LayerResults in the order of ``layers``.
+
+    One process per GPU (``group``: torch.distributed group): the tensors are dealt out to the ranks by partition_layers (longest
+    first onto the least loaded rank; replicas, no collective on the data path), each rank runs its own ones as above, and
+    every rank gets the list of LayerRecords of ALL tensors (K-sized results; ``.result`` holds the device tensors on the rank
+    that made them).  ``layers[i]`` may be None for tensors of other ranks (then pass ``sizes``, the lengths of all tensors).
+    Tensors of ``shard_above`` weights or more are not dealt out but sharded: every rank passes its shard
+    (sharding.shard_bounds) and they go through the sharded fit (``comm``: sharding.RcclComm) -- same results either way.
+    ``_compress``: the per-tensor function (tests put the CPU oracle here to rehearse the dealing without a GPU)."""
+    layers = list(layers)
+    if group is None:
+        if _compress is not None and _compress is not compress_layer:
+            return [_compress(t, **kw) for t in layers]
+        return _compress_layers_local(layers, workers=workers, **kw)
+    return _compress_layers_ranks(layers, sizes, workers, group, shard_above, comm, _compress or compress_layer, kw)
+
