@@ -51,6 +51,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, choices=(3, 4), default=3,
+                    help="BASELINE.json configs[i]: 3 = the 25 M vector at K = 256 (the headline, default); 4 = the 122 tensors of a GPT-2-small-sized "
+                         "model (124 M weights), K = 16 per layer, full prune -> quantize -> Huffman pipeline, the tensors dealt out to the GPUs")
+    ap.add_argument("--shard-above", type=int, default=0, help="--config 4: tensors of this many weights or more are sharded over all GPUs (the sharded "
+                                                                "fit) instead of dealt out whole; 0 = deal out everything")
+    ap.add_argument("--workers", type=int, default=8, help="--config 4: tensors side by side per GPU (host threads, a stream each)")
     ap.add_argument("--n", type=int, default=N_PER_GPU, help="weights per GPU")
     ap.add_argument("--bits", type=int, default=8)
     ap.add_argument("--mode", default="density")
@@ -91,7 +97,7 @@ def cpu_baseline(args, w_full: np.ndarray):
     except Exception:
         have_sklearn = False
     t0 = time.perf_counter()
-    libcalls.prune_weigth(w, args.q, True)
+    mask_cpu = libcalls.prune_weigth(w, args.q, True)
     flat = w.ravel()
     cdfs = orc.get_weight_distribution(flat[flat != 0]) if args.mode == "density" else None
     space = orc.init_space(w, args.bits, args.mode, cdfs)
@@ -109,11 +115,236 @@ def cpu_baseline(args, w_full: np.ndarray):
         "value": n / dt, "unit": "weights/s", "cores": threads, "kind": "port",
         "sample": f"{'the whole vector' if n == w_full.size else f'prefix: first {n} weights of the same vector'}, same pipeline (prune q={args.q} sigma, CDF, "
                   f"{args.mode} init, bits={args.bits}, Lloyd to convergence: {n_iter} iterations) in {dt:.2f} s; {impl}",
-    }
+    }, km, mask_cpu, threads
+
+
+def parity_record(args, res, km_cpu, mask_cpu, n_cpu, threads):
+    """The GPU step's result next to the CPU leg's (scikit-learn, float32 running sums, `threads` threads: the reference's arithmetic,
+    run-to-run reproducible only on one thread) and next to the committed full-size golden record made by the reference itself on one
+    thread (tests/golden/ref_goldens_25m.json, read as data)."""
+    import hashlib
+
+    m = res.model
+    cg = m.cluster_centers_.ravel().astype(np.float64)
+    out = {"n_iter_gpu": int(m.n_iter_)}
+    lab_g = m.labels_
+    hist_g = np.bincount(lab_g, minlength=cg.size)
+    if km_cpu is not None and n_cpu == lab_g.size:
+        cc = np.asarray(km_cpu.cluster_centers_, dtype=np.float64).ravel()
+        lab_c = np.asarray(km_cpu.labels_)
+        out.update({
+            "n_iter_cpu": int(km_cpu.n_iter_), "cpu_threads": threads,
+            "mask_equal": bool(np.array_equal(res.mask.cpu().numpy().astype(bool).ravel(), np.asarray(mask_cpu).ravel())) if res.mask is not None else None,
+            "max_rel_centre_err": float(np.max(np.abs(cg - cc) / np.maximum(np.abs(cc), 1e-30))),
+            "max_abs_centre_err": float(np.max(np.abs(cg - cc))),
+            "hist_l1": int(np.abs(hist_g - np.bincount(lab_c, minlength=cg.size)).sum()),
+            "labels_differing": int(np.count_nonzero(lab_g != lab_c)),
+        })
+    gp = os.path.join(ROOT, "tests", "golden", "ref_goldens_25m.json")
+    if os.path.exists(gp) and args.n == N_PER_GPU and (args.bits, args.mode, args.q) == (8, "density", 1.0):
+        g = json.load(open(gp))
+        lab_sha = hashlib.sha256(lab_g.astype(np.int32).tobytes()).hexdigest()
+        cbits = [int(v) for v in m.cluster_centers_.ravel().view(np.uint32)]
+        gold = {"source": "tests/golden/ref_goldens_25m.json"}
+        if "oracle_B" in g:
+            b = g["oracle_B"]
+            gold["mode_b_bit_exact"] = bool(b["n_iter"] == m.n_iter_ and b["centers_bits"] == cbits and b["labels_sha256_int32"] == lab_sha)
+            gold["mode_b_vs_reference"] = b.get("vs_reference")
+        r = g["reference"]
+        cr = np.array(r["centers_bits"], dtype=np.uint32).view(np.float32).astype(np.float64)
+        gold.update({"n_iter_reference_one_thread": r["n_iter"], "reference_bit_exact": bool(r["n_iter"] == m.n_iter_ and r["centers_bits"] == cbits and r["labels_sha256_int32"] == lab_sha),
+                     "max_rel_centre_err_vs_reference": float(np.max(np.abs(cg - cr) / np.maximum(np.abs(cr), 1e-30))),
+                     "hist_l1_vs_reference": int(np.abs(hist_g - np.array(r["bincount"])).sum())})
+        out["golden"] = gold
+    return out
+
+
+def _init_ranks(args):
+    """(torch, rank, world, device, group, comm, comm_note): one process per GPU, RCCL through torch.distributed and -- for the data-path
+    exchange of sharded fits -- the library's own communicator."""
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0 and world == 1 and args.gpus > 1:
+        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    group = comm = comm_note = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend)
+        group = dist.group.WORLD
+    return torch, rank, world, dev, group, comm, comm_note
+
+
+def cpu_baseline_config4(args, layers):
+    """The reference's CPU path on a stated subset of configs[4]: the ten tensors of transformer block 0 (7.1 M of the 124.4 M
+    weights: the four matrix shapes and the six 1-D tensors every block repeats), same seeds as the GPU run."""
+    from oracle import libcalls
+    from oracle import oracle as orc
+    from neural_network_compression_amd import synth
+
+    threads = min(len(os.sched_getaffinity(0)), 16)
+    sub = [(i, name, shape) for i, (name, shape) in enumerate(layers) if name.startswith("h0.")]
+    ws = [synth.weights(shape, 5000 + i) for i, _, shape in sub]
+    n = sum(w.size for w in ws)
+    iters = 0
+    t0 = time.perf_counter()
+    for w in ws:
+        libcalls.prune_weigth(w, args.q, True)
+        space = orc.init_space(w, 4, "linear")
+        _, km = libcalls.quantize(w, np.asarray(space, dtype=np.float32), n_threads=threads)
+        orc.huffman_lengths(np.bincount(km.labels_, minlength=16))
+        iters += int(km.n_iter_)
+    dt = time.perf_counter() - t0
+    import sklearn
+
+    return {"value": n / dt, "unit": "weights/s", "cores": threads, "kind": "port",
+            "sample": f"block 0 of the layer list ({len(ws)} of 122 tensors, {n} of 124419840 weights): prune q={args.q} sigma, linear init, bits=4, Lloyd to "
+                      f"convergence ({iters} iterations), index histogram, Huffman lengths, one tensor after the other as Trainer.quantize does, in {dt:.2f} s; "
+                      f"numpy {np.__version__} + scikit-learn {sklearn.__version__} KMeans(lloyd), {threads} threads"}
+
+
+def main_config4(args):
+    """BASELINE configs[4]: synthetic 124 M-parameter layer list (GPT-2-small-sized), K = 16 per layer, full prune -> quantize -> Huffman
+    pipeline; the tensors are dealt out to the GPUs (pipeline.compress_layers(group=...): replicas, no data-path collective; --shard-above
+    adds the sharded fit for the longest ones).  The total work is fixed, so this is a STRONG-scaling line."""
+    torch, rank, world, dev, group, comm, comm_note = _init_ranks(args)
+    from neural_network_compression_amd import _native as nat
+    from neural_network_compression_amd import pipeline, sharding, synth
+
+    L = nat.load()
+    layers = synth.gpt2_small_layers()
+    sizes = [int(np.prod(shape)) for _, shape in layers]
+    n_total = sum(sizes)
+    shard_above = args.shard_above if args.shard_above > 0 else None
+    owner = pipeline.partition_layers(sizes, world, shard_above)
+    if group is not None and args.backend == "nccl" and any(o < 0 for o in owner) and not args.python_exchange:
+        import torch.distributed as dist
+
+        try:
+            comm = sharding.RcclComm(group, dev)
+        except Exception as e:  # noqa: BLE001
+            comm_note = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+    held = []
+    for i, (name, shape) in enumerate(layers):
+        if owner[i] == rank:
+            held.append(torch.from_numpy(synth.weights(shape, 5000 + i)).to(dev).reshape(-1))
+        elif owner[i] < 0:
+            lo, hi = sharding.shard_bounds(sizes[i], world, rank)
+            held.append(torch.from_numpy(synth.weights((hi - lo,), 5000 + i, start=lo)).to(dev))
+        else:
+            held.append(None)
+    kw = dict(q=args.q, bits=4, mode="linear", huffman=True, want_values=True)
+
+    def step(workers=args.workers):
+        mine = [None if t is None else t.clone() for t in held]     # prune works in place; the copies are inside the timed region
+        if group is None:
+            return pipeline.compress_layers(mine, workers=workers, **kw)
+        return pipeline.compress_layers(mine, workers=workers, group=group, sizes=sizes, shard_above=shard_above, comm=comm, **kw)
+
+    def barrier():
+        if group is not None:
+            import torch.distributed as dist
+
+            dist.barrier(group=group)
+        torch.cuda.synchronize(dev)
+
+    res = step()
+    for _ in range(args.warmup):
+        res = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if group is not None:
+        import torch.distributed as dist
+
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+    dt = float(tmax.item())
+    # one more step, one tensor after the other, with HIP events around the assignment pass of every tensor (outside the timed region)
+    nat.check(L.nnc_profile_tags(1 << 2))
+    nat.check(L.nnc_profile_begin(256))
+    step(workers=1)
+    torch.cuda.synchronize(dev)
+    ms_buf, tag_buf, cnt = (ctypes.c_float * 256)(), (ctypes.c_int32 * 256)(), ctypes.c_int64(0)
+    nat.check(L.nnc_profile_end(ms_buf, tag_buf, 256, ctypes.byref(cnt)))
+    nat.check(L.nnc_profile_tags(0xFFFFFFFF))
+    lab_ms = np.array(ms_buf[:min(cnt.value, 256)], dtype=np.float64)
+    if rank == 0:
+        if group is None:
+            n_iter = sum(r.model.n_iter_ for r in res if r.model is not None)
+            bits = sum(int(r.total_bits or 0) for r in res)
+            passed = sum(1 for r in res if r.model is None)
+        else:
+            n_iter = sum(r.n_iter for r in res)
+            bits = sum(int(r.total_bits or 0) for r in res)
+            passed = sum(1 for r in res if r.centers is None)
+        per_rank = [sum(1 for o in owner if o == r) for r in range(world)]
+        mine_long = [sizes[i] for i, o in enumerate(owner) if o in (0, -1) and sizes[i] > 4096]
+        lab_bytes = sum((4 + 1 + 4) * (n if owner[i] >= 0 else -(-n // world)) for i, n in enumerate(sizes) if owner[i] in (0, -1) and n > 4096)
+        roof = {"bound": "hbm", "kernel": "k_assign<labels> over rank 0's tensors of more than 4096 weights (final E-step: 4 B read + 1 B centroid index + 4 B decoded "
+                                         "value per weight), one tensor after the other in one extra step",
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "launches_timed": int(lab_ms.size), "achieved": None, "frac": None}
+        if lab_ms.size == len(mine_long) and lab_ms.size:
+            roof["achieved"] = lab_bytes / (lab_ms.sum() * 1e-3) / 1e9
+            roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+            roof["algorithmic_bytes"] = int(lab_bytes)
+            roof["kernel_ms_total"] = float(lab_ms.sum())
+        # the bytes no implementation could avoid (see the configs[3] line): per weight 8+8+9+8 + 4+1+4, per surviving weight 12; short tensors as one read + write
+        step_bytes = n_total * (8 + 8 + 9 + 8 + 4 + 1 + 4) + int(0.32 * n_total) * 12
+        out = {
+            "metric": "weights/sec through prune+k-means (K=16 per layer) + Huffman, whole model",
+            "value": n_total * args.steps / dt, "unit": "weights/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"configs[4]: synthetic GPT-2-small-sized layer list, 122 tensors, {n_total} fp32 weights in total (the same total at any number of GPUs), "
+                            f"per tensor prune q={args.q} sigma -> linear-init k-means bits=4 (K=16) to convergence -> labels+values -> index histogram -> Huffman lengths",
+                "tensors": len(sizes), "weights_total": n_total, "lloyd_iterations_total": int(n_iter), "huffman_bits_per_weight": bits / n_total,
+                "passed_through": passed,
+                "parallelism": (f"layers dealt out to {world} ranks (longest first), {args.workers} streams per rank" if world > 1 else f"single GPU, {args.workers} streams")
+                               + (f"; tensors >= {shard_above} weights sharded over all ranks" if shard_above and world > 1 else ""),
+                "tensors_per_rank": per_rank, "tensors_sharded": sum(1 for o in owner if o < 0),
+                "exchange": None if not any(o < 0 for o in owner) else ("rccl-in-library" if comm is not None else "torch.distributed"),
+                "rccl_world": (int(L.nnc_comm_world(comm.handle)) if comm is not None else None),
+                "backend": (args.backend if world > 1 else None),
+            },
+            "roofline": roof,
+            "roofline_step": {"bound": "hbm", "unavoidable_bytes_per_step": int(step_bytes), "achieved": step_bytes / (dt / args.steps) / 1e9, "peak": HBM_PEAK_GBS * world,
+                              "unit": "GB/s", "frac": step_bytes / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world),
+                              "note": "122 chains of short dependent launches: latency, not bandwidth, bounds this configuration"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_config4(args, layers)
+        print(json.dumps(out))
+    if comm is not None:
+        comm.close()
+    if group is not None:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
 
 
 def main():
     args = parse()
+    if args.config == 4:
+        return main_config4(args)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -236,6 +467,20 @@ def main():
 
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
     dt = float(tmax.item())
+    # N > 1: every rank must have run the same fit (the status is replicated: same iterations, events, centres); checked, not assumed
+    agreement = None
+    if group is not None and res.model is not None:
+        import hashlib
+        import torch.distributed as dist
+
+        h = int.from_bytes(hashlib.sha256(res.model.cluster_centers_.tobytes()).digest()[:7], "little")
+        mine_t = torch.tensor([int(res.model.n_iter_), int(res.model.n_relocations_), h], dtype=torch.int64, device=dev)
+        alls = [torch.zeros_like(mine_t) for _ in range(world)]
+        dist.all_gather(alls, mine_t, group=group)
+        alls = torch.stack(alls).cpu().numpy()
+        agreement = {"n_iter": bool((alls[:, 0] == alls[0, 0]).all()), "relocations": bool((alls[:, 1] == alls[0, 1]).all()),
+                     "centres_sha": bool((alls[:, 2] == alls[0, 2]).all()), "n_iter_per_rank": [int(v) for v in alls[:, 0]]}
+        assert all(v for k, v in agreement.items() if k != "n_iter_per_rank"), f"ranks disagree on the fit: {agreement}"
 
     if rank == 0 and args.dump_durations:
         print("iteration kernels of one step, launch order (tag:us): " + " ".join(f"{int(t)}:{float(m) * 1e3:.0f}" for t, m in zip(tags_k, ms_k)), file=sys.stderr)
@@ -296,6 +541,8 @@ def main():
                 "relocations": int(res.model.n_relocations_) if res.model else 0,
                 "relocation_ties": int(getattr(res.model, "reloc_tie_", 0)) if res.model else 0,
                 "parallelism": f"shard{world}" if world > 1 else "single",
+                "rccl_world": (int(L.nnc_comm_world(comm.handle)) if comm is not None else None),
+                "backend": (args.backend if world > 1 else None),
                 "weight_iterations_per_s": n_total * n_iter * args.steps / dt,
             },
             # The k-means assignment pass over the whole vector (north_star's roofline kernel): E-step on the original order,
@@ -337,7 +584,13 @@ def main():
                 "algorithmic_bytes_per_launch": 4 * n_loc,
             }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, w_host)
+            out["cpu_baseline"], km_cpu, w_cpu, thr_cpu = cpu_baseline(args, w_host)
+            if res.model is not None:
+                out["parity"] = parity_record(args, res, km_cpu, w_cpu, w_cpu.size, thr_cpu)
+        elif world == 1 and res.model is not None:
+            out["parity"] = parity_record(args, res, None, None, 0, 0)
+        if agreement is not None:
+            out["config"]["ranks_agree"] = agreement
         print(json.dumps(out))
     if comm is not None:
         comm.close()

@@ -635,8 +635,16 @@ int nnc_huffman_lengths(const int64_t *counts, int32_t k, uint8_t *lengths_out, 
  *   nnc_huffman_decode_tables (host) first-code / count / first-index per length + symbols by (length, symbol), packed into
  *                                    nnc_huffman_decode_tables_bytes() bytes; copy them to the device for
  *   nnc_huffman_decode               one thread per chunk; *bad_dev = 1 if a chunk does not parse to its recorded length
- * The pruned zeros share one centroid, so their index is the most frequent symbol and costs one bit: the dense index stream
- * plays the role of Deep Compression's relative-index sparse format without a separate position stream.
+ * The pruned zeros share one centroid, so their index is the most frequent symbol and costs one bit in the dense stream.
+ *
+ * Relative-index sparse form (Deep Compression section 3; the format the reference's report cites, papers/lat/report.tex:327,
+ * README.md:9): only the indices that are NOT zero_symbol are stored, each with the distance to the previous stored position in
+ * delta_bits bits (stored value = distance - 1); a longer gap takes filler entries (distance 2^delta_bits, index zero_symbol).
+ * Distances restart at every chunk of NNC_CODEC_CHUNK positions.  The two entry streams are Huffman coded with the functions above.
+ *   nnc_sparse_entry_offsets         entries_off_dev[nchunks + 1] uint64: entries in front of every chunk, [nchunks] = all entries
+ *   nnc_sparse_emit                  delta_out_dev[entries] uint8, sym_out_dev[entries] (width of the labels)
+ *   nnc_sparse_expand                the inverse; *bad_dev = 1 if an entry points outside its chunk
+ * storage.py stores whichever of the dense stream and the sparse form (delta_bits 4 or 8) is smaller, per tensor.
  * ---------------------------------------------------------------------------------- */
 #define NNC_CODEC_CHUNK 1024
 int nnc_huffman_codes(const uint8_t *lengths, int32_t k, uint32_t *codes_out);
@@ -649,6 +657,11 @@ size_t nnc_huffman_decode_tables_bytes(void);
 int nnc_huffman_decode_tables(const uint8_t *lengths, int32_t k, void *tables_out, size_t tables_bytes);
 int nnc_huffman_decode(const uint32_t *words_dev, const uint64_t *chunk_off_dev, int64_t n, const void *tables_dev, int32_t k,
                        void *labels_out, int label_bytes, int32_t *bad_dev, void *stream);
+int nnc_sparse_entry_offsets(const void *labels, int label_bytes, int64_t n, int32_t zero_symbol, int32_t delta_bits, uint64_t *entries_off_dev, void *stream);
+int nnc_sparse_emit(const void *labels, int label_bytes, int64_t n, int32_t zero_symbol, int32_t delta_bits, const uint64_t *entries_off_dev,
+                    uint8_t *delta_out_dev, void *sym_out_dev, void *stream);
+int nnc_sparse_expand(const uint8_t *delta_dev, const void *sym_dev, int label_bytes, const uint64_t *entries_off_dev, int64_t n, int32_t zero_symbol,
+                      void *labels_out, int32_t *bad_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -154,6 +154,9 @@ SIGNATURES = {
     "nnc_huffman_decode_tables_bytes": (c_size, []),
     "nnc_huffman_decode_tables": (c_int, [ctypes.POINTER(ctypes.c_uint8), c_i32, c_void_p, c_size]),
     "nnc_huffman_decode": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_int, c_void_p, c_void_p]),
+    "nnc_sparse_entry_offsets": (c_int, [c_void_p, c_int, c_i64, c_i32, c_i32, c_void_p, c_void_p]),
+    "nnc_sparse_emit": (c_int, [c_void_p, c_int, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "nnc_sparse_expand": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
     "nnc_comm_unique_id": (c_int, [c_void_p, c_size]),
     "nnc_comm_init": (c_int, [ctypes.POINTER(c_void_p), c_void_p, c_size, c_i32, c_i32]),
     "nnc_comm_destroy": (c_int, [c_void_p]),

@@ -30,27 +30,61 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = SOURCES + [os.path.join(INCLUDE, "nnc.h"), os.path.join(CSRC, "nnc_lloyd.hpp")]
+    deps = SOURCES + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _headers():
+    return [os.path.join(INCLUDE, "nnc.h")] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp"))
+
+
+def _flags():
+    return (["--offload-arch=gfx950", "-O3", "-std=c++17",
+             "-ffp-contract=off",  # the reference arithmetic is unfused float32; never contract
+             "-fPIC", "-I", INCLUDE]
+            + (["-DNNC_DIAG"] if DIAG else []) + (["-DNNC_NO_HELP"] if os.environ.get("NNC_NO_HELP") else []))
+
+
 def build_native(force: bool = False, verbose: bool = False) -> str:
+    """One object per translation unit under csrc/_obj/ (compiled side by side, re-made only when the unit or a header
+    changed), then one link.  The library is built aside and renamed: another process never maps a half-written file."""
     if not force and not is_stale():
         return LIB
-    tmp = f"{LIB}.{os.getpid()}.tmp"   # built aside and renamed: another process never maps a half-written library
-    cmd = [
-        hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17",
-        "-ffp-contract=off",  # the reference arithmetic is unfused float32; never contract
-        "-fPIC", "-shared", "-I", INCLUDE, "-o", tmp,
-    ] + (["-DNNC_DIAG"] if DIAG else []) + (["-DNNC_NO_HELP"] if os.environ.get("NNC_NO_HELP") else []) + SOURCES + EXTRA_LIBS
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = hipcc_path()
+    objdir = os.path.join(CSRC, "_obj_diag" if DIAG else "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(h) for h in _headers())
+    log = []
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            return obj
+        tmp = f"{obj}.{os.getpid()}.tmp"
+        cmd = [hipcc] + _flags() + ["-c", src, "-o", tmp]
+        proc = subprocess.run(cmd, capture_output=True, text=True)
+        if proc.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+        os.replace(tmp, obj)
+        log.append(proc.stdout + proc.stderr)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    tmp = f"{LIB}.{os.getpid()}.tmp"
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs + EXTRA_LIBS
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         if os.path.exists(tmp):
             os.remove(tmp)
-        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+        raise RuntimeError("hipcc (link) failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
     os.replace(tmp, LIB)
     if verbose:
-        print(proc.stdout + proc.stderr)
+        print("".join(log) + proc.stdout + proc.stderr)
     return LIB
 
 

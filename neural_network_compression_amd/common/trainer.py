@@ -200,7 +200,10 @@ class Trainer(ABC):
         return accuracies
 
     def store_report(self, directory: str) -> None:
-        """Zero counts per layer (the plots of the reference's report are out of scope)."""
+        """Zero counts per layer, as the reference's report.txt (common/trainer.py:154-175; its plots are out of scope).  After
+        ``quantize`` the network is also written in its stored form (storage.save_compressed: codebook + Huffman-coded centroid
+        indices, dense or relative-index sparse, whichever is smaller per tensor -> ``weights.nnc``) and the report gains what Deep
+        Compression reports: bits per weight of every tensor and the compression ratio against 32-bit weights."""
         pathlib.Path(directory).mkdir(parents=True, exist_ok=True)
         report = ""
         for layer_name, layer in self.neural_network.get_config().items():
@@ -211,6 +214,25 @@ class Trainer(ABC):
             report += f"layer: {layer_name}\n"
             report += f"zeroed weights: {int((weight_layer == 0).sum())}\ntotal weights: {weight_layer.numel()}\n"
             report += f"zeroed biases: {int((bias_layer == 0).sum())}\ntotal weights: {bias_layer.numel()}\n\n"
+        models = getattr(self, "quantized_models_by_layer", None)
+        if models:
+            from .. import storage
+
+            stored = {}
+            for layer_name, layer in self.neural_network.get_config().items():
+                if layer not in models:
+                    continue
+                for kind, t, m in zip(("weights", "biases"), layer.get_weights(), models[layer]):
+                    stored[f"{layer_name}.{kind}"] = (tuple(t.shape), m, t if m is None else None)
+            rep = {}
+            storage.save_compressed(f"{directory}/weights.nnc", stored, report=rep)
+            self.compression_report = rep
+            for name, r in rep.items():
+                if name != "total":
+                    report += f"stored {name}: {r['bytes']} bytes, {r['bits_per_weight']:.3f} bits per weight ({r['form']}, {r['k']} centroids)\n"
+            t = rep["total"]
+            report += (f"stored network: {t['bytes']} bytes for {t['n']} weights = {t['bits_per_weight']:.3f} bits per weight; "
+                       f"compression ratio {t['compression_ratio']:.1f}x against float32\n")
         with open(f"{directory}/report.txt", "w") as f:
             f.write(report)
 

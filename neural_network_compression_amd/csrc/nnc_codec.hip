@@ -284,3 +284,179 @@ extern "C" int nnc_huffman_decode(const uint32_t *words_dev, const uint64_t *chu
     if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
     return NNC_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Relative-index sparse form (Deep Compression section 3, the format the reference's report cites: papers/lat/report.tex:327,
+// README.md:9): only the weights whose centroid index is NOT the zero cluster's are stored, each as (distance to the previous
+// stored position, centroid index); the distance has `delta_bits` bits (stored value = distance - 1, distance in 1 .. D = 2^bits),
+// and a gap longer than D takes filler entries (distance D, index = the zero cluster's) -- the paper's "padding zero".
+// Distances restart at every chunk of NNC_CODEC_CHUNK positions (the position in front of a chunk counts as stored), so chunks
+// encode and decode independently; entries_off[c] = number of entries in front of chunk c.  The two entry streams (distances,
+// indices) are then Huffman coded by the functions above, as the paper does.
+//
+// One workgroup per chunk, a thread per four consecutive positions.  sp_scan_chunk: for each of a thread's positions the
+// number of entries it emits (fillers + 1, or 0 for a zero-cluster position) and the distance its own entry carries.
+template <typename LT>
+__device__ __forceinline__ unsigned sp_scan_chunk(const LT *__restrict__ labels, long long n, long long base, int zero, int dbits, int *prev_s /*[4] LDS*/,
+                                                  unsigned (&ent)[4], unsigned (&dist)[4], int (&sym)[4])
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const unsigned D = 1u << dbits;
+    int last = -1; // last stored position (chunk-relative) among this thread's four, -1 if none
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const long long g = base + tid * 4 + u;
+        sym[u] = (g < n) ? (int)labels[g] : zero;
+        if (sym[u] != zero) last = tid * 4 + u;
+    }
+    // previous stored position in front of this thread: inclusive max-scan over threads, shifted by one
+    int inc = last;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o && t > inc) inc = t; }
+    if (lane == 63) prev_s[wv] = inc;
+    __syncthreads();
+    int prev = __shfl_up(inc, 1);
+    if (lane == 0) prev = -1;
+    for (int w = 0; w < wv; w++) if (prev_s[w] > prev) prev = prev_s[w];
+    unsigned total = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        ent[u] = 0; dist[u] = 0;
+        if (sym[u] != zero) {
+            const unsigned gap = (unsigned)(tid * 4 + u - prev); // >= 1
+            const unsigned fill = (gap - 1) >> dbits;
+            ent[u] = fill + 1;
+            dist[u] = gap - fill * D; // 1 .. D
+            prev = tid * 4 + u;
+            total += ent[u];
+        }
+    }
+    return total;
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void k_sparse_count(const LT *__restrict__ labels, long long n, int zero, int dbits, unsigned long long *__restrict__ chunk_entries)
+{
+    __shared__ int prev_s[4];
+    __shared__ unsigned wsum[4];
+    unsigned ent[4], dist[4];
+    int sym[4];
+    unsigned mine = sp_scan_chunk<LT>(labels, n, (long long)blockIdx.x * CODEC_CHUNK, zero, dbits, prev_s, ent, dist, sym);
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) chunk_entries[blockIdx.x] = (unsigned long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+template <typename LT>
+__global__ __launch_bounds__(256) void k_sparse_emit(const LT *__restrict__ labels, long long n, int zero, int dbits, const unsigned long long *__restrict__ entries_off,
+                                                     uint8_t *__restrict__ delta_out, LT *__restrict__ sym_out)
+{
+    __shared__ int prev_s[4];
+    __shared__ unsigned wave_tot[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned ent[4], dist[4];
+    int sym[4];
+    const unsigned mine = sp_scan_chunk<LT>(labels, n, (long long)blockIdx.x * CODEC_CHUNK, zero, dbits, prev_s, ent, dist, sym);
+    unsigned inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    unsigned long long pos = entries_off[blockIdx.x] + (inc - mine);
+    for (int w = 0; w < wv; w++) pos += wave_tot[w];
+    const uint8_t full = (uint8_t)((1u << dbits) - 1u);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (!ent[u]) continue;
+        for (unsigned f = 0; f + 1 < ent[u]; f++) { delta_out[pos] = full; sym_out[pos] = (LT)zero; pos++; } // padding zeros
+        delta_out[pos] = (uint8_t)(dist[u] - 1u);
+        sym_out[pos] = (LT)sym[u];
+        pos++;
+    }
+}
+
+// The inverse: a chunk's positions are filled with the zero cluster's index, then its entries are walked (running sum of the
+// distances, 256 entries a round) and written.  *bad = 1 if an entry points outside its chunk.
+template <typename LT>
+__global__ __launch_bounds__(256) void k_sparse_expand(const uint8_t *__restrict__ delta, const LT *__restrict__ sym, const unsigned long long *__restrict__ entries_off,
+                                                       long long n, int zero, LT *__restrict__ labels_out, int *__restrict__ bad)
+{
+    __shared__ unsigned wave_tot[4];
+    __shared__ unsigned carry_s;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long long base = (long long)blockIdx.x * CODEC_CHUNK;
+    const unsigned len = (unsigned)((base + CODEC_CHUNK < n ? base + CODEC_CHUNK : n) - base);
+    for (unsigned i = tid; i < len; i += 256) labels_out[base + i] = (LT)zero;
+    if (tid == 0) carry_s = 0;
+    __syncthreads(); // the fill is visible to the whole workgroup before any entry is written over it
+    const unsigned long long e0 = entries_off[blockIdx.x], e1 = entries_off[blockIdx.x + 1];
+    for (unsigned long long e = e0; e < e1; e += 256) {
+        const bool have = e + tid < e1;
+        const unsigned d = have ? (unsigned)delta[e + tid] + 1u : 0u;
+        unsigned inc = d;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        unsigned p = carry_s + inc;
+        for (int w = 0; w < wv; w++) p += wave_tot[w];
+        if (have) {
+            if (p - 1u < len) labels_out[base + p - 1u] = sym[e + tid]; // position = (chunk start - 1) + running sum
+            else *bad = 1;
+        }
+        __syncthreads();
+        if (tid == 255) carry_s = p;
+        __syncthreads();
+    }
+}
+
+// entries_off_dev: (nchunks + 1) uint64; on return entries_off_dev[c] = entries in front of chunk c, [nchunks] = all entries.
+extern "C" int nnc_sparse_entry_offsets(const void *labels, int label_bytes, int64_t n, int32_t zero_symbol, int32_t delta_bits, uint64_t *entries_off_dev, void *stream)
+{
+    if (n < 0 || !entries_off_dev || (n > 0 && !labels) || (label_bytes != 1 && label_bytes != 2) || delta_bits < 1 || delta_bits > 8 || zero_symbol < 0 || zero_symbol >= NNC_KMAX)
+        return nnc_set_error_(NNC_EINVAL, "nnc_sparse_entry_offsets: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long nchunks = (long long)nnc_codec_chunks(n);
+    unsigned long long *co = reinterpret_cast<unsigned long long *>(entries_off_dev);
+    if (nchunks > 0) {
+        if (label_bytes == 1) hipLaunchKernelGGL((k_sparse_count<uint8_t>), dim3((unsigned)nchunks), dim3(256), 0, s, reinterpret_cast<const uint8_t *>(labels), (long long)n, (int)zero_symbol, (int)delta_bits, co);
+        else hipLaunchKernelGGL((k_sparse_count<uint16_t>), dim3((unsigned)nchunks), dim3(256), 0, s, reinterpret_cast<const uint16_t *>(labels), (long long)n, (int)zero_symbol, (int)delta_bits, co);
+    }
+    hipLaunchKernelGGL(k_scan_bits, dim3(1), dim3(1024), 0, s, co, nchunks);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    return NNC_OK;
+}
+
+// delta_out_dev: uint8[entries] (distance - 1); sym_out_dev: entries indices of the labels' own width.
+extern "C" int nnc_sparse_emit(const void *labels, int label_bytes, int64_t n, int32_t zero_symbol, int32_t delta_bits, const uint64_t *entries_off_dev,
+                               uint8_t *delta_out_dev, void *sym_out_dev, void *stream)
+{
+    if (n < 0 || !entries_off_dev || (n > 0 && (!labels || !delta_out_dev || !sym_out_dev)) || (label_bytes != 1 && label_bytes != 2) || delta_bits < 1 || delta_bits > 8 ||
+        zero_symbol < 0 || zero_symbol >= NNC_KMAX)
+        return nnc_set_error_(NNC_EINVAL, "nnc_sparse_emit: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const long long nchunks = (long long)nnc_codec_chunks(n);
+    if (nchunks == 0) return NNC_OK;
+    const unsigned long long *co = reinterpret_cast<const unsigned long long *>(entries_off_dev);
+    if (label_bytes == 1) hipLaunchKernelGGL((k_sparse_emit<uint8_t>), dim3((unsigned)nchunks), dim3(256), 0, s, reinterpret_cast<const uint8_t *>(labels), (long long)n, (int)zero_symbol, (int)delta_bits, co, delta_out_dev, reinterpret_cast<uint8_t *>(sym_out_dev));
+    else hipLaunchKernelGGL((k_sparse_emit<uint16_t>), dim3((unsigned)nchunks), dim3(256), 0, s, reinterpret_cast<const uint16_t *>(labels), (long long)n, (int)zero_symbol, (int)delta_bits, co, delta_out_dev, reinterpret_cast<uint16_t *>(sym_out_dev));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    return NNC_OK;
+}
+
+extern "C" int nnc_sparse_expand(const uint8_t *delta_dev, const void *sym_dev, int label_bytes, const uint64_t *entries_off_dev, int64_t n, int32_t zero_symbol,
+                                 void *labels_out, int32_t *bad_dev, void *stream)
+{
+    if (n < 0 || !entries_off_dev || !bad_dev || (n > 0 && !labels_out) || (label_bytes != 1 && label_bytes != 2) || zero_symbol < 0 || zero_symbol >= NNC_KMAX)
+        return nnc_set_error_(NNC_EINVAL, "nnc_sparse_expand: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(bad_dev, 0, 4, s) != hipSuccess) return nnc_set_error_(NNC_EHIP, "nnc_sparse_expand: memset");
+    const long long nchunks = (long long)nnc_codec_chunks(n);
+    if (nchunks == 0) return NNC_OK;
+    const unsigned long long *co = reinterpret_cast<const unsigned long long *>(entries_off_dev);
+    if (label_bytes == 1) hipLaunchKernelGGL((k_sparse_expand<uint8_t>), dim3((unsigned)nchunks), dim3(256), 0, s, delta_dev, reinterpret_cast<const uint8_t *>(sym_dev), co, (long long)n, (int)zero_symbol, reinterpret_cast<uint8_t *>(labels_out), bad_dev);
+    else hipLaunchKernelGGL((k_sparse_expand<uint16_t>), dim3((unsigned)nchunks), dim3(256), 0, s, delta_dev, reinterpret_cast<const uint16_t *>(sym_dev), co, (long long)n, (int)zero_symbol, reinterpret_cast<uint16_t *>(labels_out), bad_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return nnc_set_error_(NNC_EHIP, hipGetErrorString(e));
+    return NNC_OK;
+}

@@ -222,7 +222,8 @@ def fit_reference(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = 
     return model, vals
 
 
-REF_LARGE_NMAX = (1 << 24) - 1   # float32 member counts (scikit-learn's weight_in_clusters) are exact up to here
+F32_COUNT_MAX = 1 << 24           # scikit-learn counts members in float32 (weight_in_clusters += 1.0f, _k_means_lloyd.pyx:216): the count of a
+#                                   cluster stops at 2^24 (16 777 216 + 1 rounds back to 16 777 216); the pruned zeros of a 25 M tensor get there
 
 
 def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: float = TOL, want_values: bool = True, stats=None):
@@ -233,15 +234,15 @@ def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: fl
     order (_k_means_lloyd.pyx:215-218, one thread).  Here they are exactly that (nnc_ref_sums_f32: one wave per cluster walking
     the label vector; an iteration costs the largest cluster times a few nanoseconds -- the zero cluster of a pruned fc1 about a
     millisecond).  The E-step is the device's (bit-exact float32 arg-min, the same as everywhere); everything K-sized --
-    float32 member counts, relocation of empty clusters with ``numpy.argpartition`` itself on the squared distances in sample order
+    float32 member counts (they stop at 2^24, as scikit-learn's do), relocation of empty clusters with ``numpy.argpartition`` itself on the squared distances in sample order
     (_k_means_common.pyx:167-211), averaging by float32(1 / count), the shift, NumPy's pairwise float32 sum, the two stopping
     rules (_kmeans.py:705-733) -- runs in NumPy on the host from 12 bytes per centre per iteration.  One GPU."""
     x = x.reshape(-1)
     ops._require_cuda(x, "x", torch.float32)
     init = np.ascontiguousarray(np.asarray(init, dtype=np.float32).reshape(-1))
     n, k = x.numel(), int(init.size)
-    if not (1 <= k <= n <= REF_LARGE_NMAX):
-        raise ValueError(f"fit_reference_large: n={n}, k={k} outside k <= n <= {REF_LARGE_NMAX}")
+    if not (1 <= k <= n):
+        raise ValueError(f"fit_reference_large: n={n}, k={k} outside k <= n")
     km = DeviceKMeans(x, init, max_iter=max_iter, tol=tol, sort=False, stats=stats)   # statistics, tolerance, E-step tables; its Lloyd loop is not used
     L, dev, stream = km.L, km.dev, km.stream
     lb = 1 if k <= 256 else 2
@@ -263,7 +264,7 @@ def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: fl
             nat.check(L.nnc_labels_equal(lab.data_ptr(), labels_old.data_ptr(), n, lb, flag.data_ptr(), stream))
         host = blk.cpu().numpy()
         sums = host[8 * k:].view(np.float32).copy()
-        wic = host[: 8 * k].view(np.int64).astype(np.float32)   # (scikit-learn counts in float32; exact here)
+        wic = np.minimum(host[: 8 * k].view(np.int64), F32_COUNT_MAX).astype(np.float32)   # scikit-learn's float32 running count, saturation included
         if labels_old is not None:
             same = bool(int(flag.item()))
         empty = np.flatnonzero(wic == 0)
@@ -272,11 +273,12 @@ def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: fl
             d = km.assign(which=0, labels=False, distances=True)[2].cpu().numpy()
             far = np.argpartition(d, -empty.size)[: -empty.size - 1: -1]
             if np.max(d) != 0:
-                ds = np.sort(d)
                 n_reloc += 1
                 multi += int(empty.size > 1)
-                if empty.size < d.size and ds[-empty.size] == ds[-empty.size - 1] and ds[-empty.size] != 0:
-                    ties += 1
+                if empty.size < d.size:
+                    cut = np.partition(d, [d.size - empty.size - 1, d.size - empty.size])[d.size - empty.size - 1: d.size - empty.size + 1]
+                    if cut[0] == cut[1] and cut[1] != 0:   # two samples equally far at the selection cut: introselect decides
+                        ties += 1
                 idx = torch.from_numpy(far.astype(np.int64)).to(dev)
                 xf = (x[idx].cpu().numpy() - x_mean).astype(np.float32)
                 lf = lab[idx].cpu().numpy().astype(np.int64) & (0xFF if lb == 1 else 0xFFFF)
@@ -328,8 +330,9 @@ def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: fl
 
 def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "auto", group=None, **kw):
     """The fit behind get_quantized_weight / compress_layer.  ``arith``: "reference" = scikit-learn's float32 running sums
-    in sample order (one GPU; one launch for short tensors, fit_reference_large beyond: slow, for callers who want the
-    reference's centres bit for bit), "fixed" = exact fixed-point sums (any size, any number of GPUs), "auto" = reference
+    in sample order, i.e. scikit-learn on ONE OpenMP thread (with more threads its chunk-wise partial sums are reduced in arrival
+    order and the result is not reproducible) -- one GPU; one launch for short tensors, fit_reference_large beyond: slow,
+    for callers who want the reference's centres bit for bit --, "fixed" = exact fixed-point sums (any size, any number of GPUs), "auto" = reference
     where the one-launch form applies, fixed otherwise."""
     if arith not in ("auto", "reference", "fixed"):
         raise ValueError("arith must be 'auto', 'reference' or 'fixed'")
@@ -341,8 +344,8 @@ def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "au
             raise ValueError("arith='reference' is a single-GPU fit")
         if arith == "reference" and not reference_fit_applies(x.numel(), k, group):
             # beyond the one-launch form: sample-order sums on the device, the K-sized steps in NumPy (slow, exact, opt-in)
-            return fit_reference_large(x, init, want_values=want_values, stats=kw.get("stats"))
-        return fit_reference(x, init, want_values=want_values)
+            return fit_reference_large(x, init, want_values=want_values, stats=kw.get("stats"), **{a: kw[a] for a in ("max_iter", "tol") if a in kw})
+        return fit_reference(x, init, want_values=want_values, **{a: kw[a] for a in ("max_iter", "tol") if a in kw})
     model, vals = DeviceKMeans(x, init, group=group, **kw).fit(want_values=want_values)
     model.arith_ = "fixed"
     return model, vals
