@@ -128,10 +128,29 @@ def stage_oracle(accum):
     print(f"[oracle {accum}] n_iter={km.n_iter_} in {time.time() - t0:.0f} s", flush=True)
 
 
+def quality(w64, centers_bits, labels):
+    """Permutation-free measures of a fit (index permutations and different local optima make index-by-index numbers meaningless
+    once two trajectories have parted): the k-means objective in float64, the centres as a sorted list, how many lie either side
+    of the pruned gap, how far a centre is from the exact mean of its members."""
+    c = np.array(centers_bits, dtype=np.uint32).view(np.float32)
+    q = c[labels].astype(np.float64)
+    cnt = np.bincount(labels, minlength=c.size)
+    s = np.bincount(labels, weights=w64, minlength=c.size)
+    return {"inertia_f64": float(((w64 - q) ** 2).sum()), "centres_negative": int((c < 0).sum()), "centres_positive": int((c > 0).sum()),
+            "max_abs_centre_minus_member_mean": float(np.abs(c - s / np.maximum(cnt, 1)).max())}
+
+
 def stage_merge():
+    from oracle import oracle as orc
+
     out = json.load(open(os.path.join(SCRATCH, "ref.json")))
     lref = np.load(os.path.join(SCRATCH, "labels_ref.npy"))
     cref = np.array(out["reference"]["centers_bits"], dtype=np.uint32).view(np.float32).astype(np.float64)
+    w = synth.weights((N,), SEED)
+    orc.prune_weigth(w, Q, True)
+    assert sha(w) == out["pruned_sha256"]
+    w64 = w.astype(np.float64)
+    out["reference"]["quality"] = quality(w64, out["reference"]["centers_bits"], lref)
     for accum in ("B", "A"):
         p = os.path.join(SCRATCH, f"oracle{accum}.json")
         if not os.path.exists(p):
@@ -146,7 +165,9 @@ def stage_merge():
             "max_abs_centre_err": float(np.max(np.abs(c - cref))),
             "centres_differing": int(np.count_nonzero(c != cref)),
             "n_iter_equal": rec["n_iter"] == out["reference"]["n_iter"],
+            "max_abs_sorted_centre_err": float(np.max(np.abs(np.sort(c) - np.sort(cref)))),
         }
+        rec["quality"] = quality(w64, rec["centers_bits"], lab)
         out[f"oracle_{accum}"] = rec
     json.dump(out, open(OUT, "w"), indent=1, sort_keys=True)
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB")

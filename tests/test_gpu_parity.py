@@ -565,34 +565,47 @@ def test_headline_25m_equals_mode_b_golden_bit_for_bit(nnc):
     assert sha(labels.astype(np.int32)) == b["labels_sha256_int32"]
     assert [int(v) for v in np.bincount(labels, minlength=257)] == b["bincount"] == [int(v) for v in r.counts]
     assert sha(r.values.cpu().numpy()) == b["quantized_sha256"]
-    assert m.n_relocations_ == b["reloc_info"].get("reloc_events", 0) and m.reloc_tie_ == b["reloc_info"].get("reloc_ties", 0)
+    assert m.n_relocations_ == b["reloc_info"].get("reloc_events", 0)
+    # (the oracle counts every pair of equal distances at a selection cut; the device only pairs of DIFFERENT values -- equal samples are interchangeable)
+    assert m.reloc_tie_ <= b["reloc_info"].get("reloc_ties", 0)
 
 
 def test_headline_25m_against_the_reference_itself(nnc):
-    """The same run against what the REFERENCE produced on the same input (its own prune_weigth / get_weight_distribution /
-    get_quantized_weight, scikit-learn on one thread; tests/golden/ref_goldens_25m.json "reference").  The device's distance from it is
-    the oracle's mode-B distance from it, measured on the CPU where both index vectors exist ("oracle_B"."vs_reference") -- the device,
-    being mode B bit for bit (test above), must reproduce those numbers exactly; they are reported and bounded here.
-    Why the iteration counts differ at this size, when they agree on every smaller golden: see DESIGN.md section 2 (float32 member
-    counts saturate at 2^24 in scikit-learn's weight_in_clusters; the pruned zeros are 17 M members of one cluster)."""
+    """The default (exact-sum) fit of the headline tensor against what the REFERENCE produced on it (scikit-learn on one thread;
+    tests/golden/ref_goldens_25m.json "reference").  At this size the two part ways -- 43 iterations and 13 relocation events here, 49
+    and 12 there -- and the cause is arithmetic alone, established on the CPU: the oracle's mode A reproduces the
+    reference bit for bit, mode A with the device's relocation rule differs from it only by two swapped indices, mode B with
+    numpy.argpartition equals mode B.  scikit-learn's float32 running sums over up to 17 M members (and its float32 member count, which
+    stops at 2^24) are 1e-4 off the members' mean; after the mass relocations of the density init that is enough to send the empty
+    clusters to other samples: another local optimum, six centres more on the negative side.  Index-by-index numbers are then
+    meaningless; what is checked: the device's result IS mode B's (bit for bit, test above) and it is at least as good a k-means
+    solution -- objective in float64 not above the reference's, every centre closer to its members' exact mean."""
     from neural_network_compression_amd import pipeline
 
     g = _golden_25m()
-    ref, vs = g["reference"], g["oracle_B"]["vs_reference"]
+    ref, ob = g["reference"], g["oracle_B"]
     w = synth.weights((g["n"],), g["seed"])
-    r = pipeline.compress_layer(dev(nnc, w).clone(), q=1.0, bits=8, mode="density", huffman=True, want_values=True)
+    x = dev(nnc, w).clone()
+    r = pipeline.compress_layer(x, q=1.0, bits=8, mode="density", huffman=True, want_values=True)
     m = r.model
-    cr = np.array(ref["centers_bits"], dtype=np.uint32).view(np.float32).astype(np.float64)
-    cg = m.cluster_centers_.ravel().astype(np.float64)
-    rel = float(np.max(np.abs(cg - cr) / np.maximum(np.abs(cr), 1e-30)))
-    l1 = int(np.abs(np.bincount(m.labels_, minlength=257) - np.array(ref["bincount"])).sum())
-    print(f"25 M, K = 257: device n_iter {m.n_iter_} / reference {ref['n_iter']}; max rel centre error {rel:.3e} "
-          f"(abs {np.max(np.abs(cg - cr)):.3e}); index histogram L1 {l1}; indices differing (oracle B, CPU) {vs['labels_differing']}")
-    assert rel == vs["max_rel_centre_err"] and l1 == vs["hist_l1"]
-    assert abs(m.n_iter_ - ref["n_iter"]) <= 2
-    scale = float(np.abs(cr).max())
-    assert np.max(np.abs(cg - cr)) <= 5e-4 * scale                    # scikit-learn's float32 summation error (ab_gap.SUMMATION_ERROR_CEILING)
-    assert vs["labels_differing"] <= 2e-3 * g["n"] and l1 <= 4e-3 * g["n"]
+    wp = x.cpu().numpy().astype(np.float64)
+    q = r.values.cpu().numpy().astype(np.float64)
+    inertia = float(((wp - q) ** 2).sum())
+    labels = m.labels_
+    c = m.cluster_centers_.ravel()
+    cnt = np.bincount(labels, minlength=257)
+    mean = np.bincount(labels, weights=wp, minlength=257) / np.maximum(cnt, 1)
+    off_mean = float(np.abs(c - mean).max())
+    cr = np.array(ref["centers_bits"], dtype=np.uint32).view(np.float32)
+    print(f"25 M, K = 257: device n_iter {m.n_iter_} / reference {ref['n_iter']}; objective {inertia:.6f} / {ref['quality']['inertia_f64']:.6f}; "
+          f"centre - member mean {off_mean:.2e} / {ref['quality']['max_abs_centre_minus_member_mean']:.2e}; centres below zero {int((c < 0).sum())} / "
+          f"{ref['quality']['centres_negative']}; sorted centres differ by up to {np.abs(np.sort(c).astype(np.float64) - np.sort(cr)).max():.3e}")
+    assert m.n_iter_ == ob["n_iter"] and ref["n_iter"] == g["oracle_A"]["n_iter"]       # 43 = mode B; the reference's 49 = mode A
+    assert g["oracle_A"]["vs_reference"]["labels_differing"] == 0 and g["oracle_A"]["vs_reference"]["centres_differing"] == 0
+    assert abs(inertia - ob["quality"]["inertia_f64"]) <= 1e-9 * inertia
+    assert inertia <= ref["quality"]["inertia_f64"]
+    assert off_mean <= ref["quality"]["max_abs_centre_minus_member_mean"]
+    assert cnt.min() > 0 and int(cnt.sum()) == g["n"]
 
 
 def test_headline_25m_in_reference_arithmetic_is_the_reference_bit_for_bit(nnc):
