@@ -182,6 +182,7 @@ DIAG_SIGNATURES = {
     "nnc_debug_clock": (c_int, [c_int, c_int, c_void_p, c_void_p]),
     "nnc_debug_reloc_fail": (c_int, [c_void_p, ctypes.POINTER(c_i32)]),
     "nnc_debug_kl_trace": (c_int, [c_void_p, c_void_p]),
+    "nnc_debug_os_trace": (c_int, [c_void_p]),
 }
 
 _lib = None

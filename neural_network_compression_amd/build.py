@@ -42,7 +42,8 @@ def _flags():
     return (["--offload-arch=gfx950", "-O3", "-std=c++17",
              "-ffp-contract=off",  # the reference arithmetic is unfused float32; never contract
              "-fPIC", "-I", INCLUDE]
-            + (["-DNNC_DIAG"] if DIAG else []) + (["-DNNC_NO_HELP"] if os.environ.get("NNC_NO_HELP") else []))
+            + (["-DNNC_DIAG"] if DIAG else []) + (["-DNNC_NO_HELP"] if os.environ.get("NNC_NO_HELP") else [])
+            + os.environ.get("NNC_EXTRA_CXXFLAGS", "").split())   # (tuning experiments on the GPU box, e.g. -DOS_THREADS=256)
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:

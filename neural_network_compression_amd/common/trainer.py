@@ -74,7 +74,12 @@ class Trainer(ABC):
 
     # ------------------------------------------------------------------ the hot path
     def quantize(self, test_dataset: LeNetDataset, with_cumulative_weight_distribution: bool,
-                 maximum_centroid_bits: int, k_means_initialization_mode: str) -> float:
+                 maximum_centroid_bits: int, k_means_initialization_mode: str, *, arith: str = "auto", reloc: str = "auto") -> float:
+        """The reference's signature (common/trainer.py:42-48) plus two keywords that select its own arithmetic where identity
+        with it is wanted (utility.get_quantized_weight): ``arith="reference"`` = scikit-learn's float32 running sums in sample
+        order on tensors of any length (centres, indices and n_iter_ then equal the reference's on one thread bit for bit; slower:
+        a host round trip per Lloyd iteration beyond 4096 weights), ``reloc="reference"`` = numpy.argpartition's own choice of the
+        far samples at an empty-cluster event.  The defaults are the order-independent exact sums and the on-device selection."""
         self.quantized_models_by_layer = {}   # layer -> [fitted model or None per tensor]: what fine_tune_centroids needs
         layers = [layer for _layer_name, layer in self.neural_network.get_config().items()]
         # The tensors of the network are independent: where the init draws nothing from NumPy's global generator (linear,
@@ -85,7 +90,7 @@ class Trainer(ABC):
         # (the reference's "not enough bits" pass-through), the error cases -- takes the reference's own sequence of calls.
         mode, bits = k_means_initialization_mode, maximum_centroid_bits
         batched = {}
-        if mode in ("linear", "density") and (mode != "density" or with_cumulative_weight_distribution) and isinstance(bits, int) and 1 <= bits <= 10:
+        if (arith, reloc) == ("auto", "auto") and mode in ("linear", "density") and (mode != "density" or with_cumulative_weight_distribution) and isinstance(bits, int) and 1 <= bits <= 10:
             from .. import pipeline
 
             todo = [(li, ti, params) for li, layer in enumerate(layers) for ti, params in enumerate(layer.get_weights())
@@ -109,7 +114,7 @@ class Trainer(ABC):
                         # the device kernels skip them instead -- same histogram, no compaction
                         cdfs = utility.get_weight_distribution(params, skip_zeros=True)
                     quantized, model = utility.get_quantized_weight(params, bits=maximum_centroid_bits,
-                                                                    mode=k_means_initialization_mode, cdfs=cdfs)
+                                                                    mode=k_means_initialization_mode, cdfs=cdfs, arith=arith, reloc=reloc)
                 quantized_weights_and_bias.append(quantized)
                 models.append(model)
             layer.set_weights(quantized_weights_and_bias)

@@ -342,8 +342,9 @@ def fit_vector(x: torch.Tensor, init, want_values: bool = True, arith: str = "au
     if arith == "reference" or (arith == "auto" and reference_fit_applies(x.numel(), k, group)):
         if group is not None:
             raise ValueError("arith='reference' is a single-GPU fit")
-        if arith == "reference" and not reference_fit_applies(x.numel(), k, group):
-            # beyond the one-launch form: sample-order sums on the device, the K-sized steps in NumPy (slow, exact, opt-in)
+        if arith == "reference" and (kw.get("reloc") == "reference" or not reference_fit_applies(x.numel(), k, group)):
+            # beyond the one-launch form (or numpy.argpartition's own pairing asked for, which needs the host in the loop): sample-order
+            # sums on the device, the K-sized steps in NumPy (slow, exact, opt-in)
             return fit_reference_large(x, init, want_values=want_values, stats=kw.get("stats"), **{a: kw[a] for a in ("max_iter", "tol") if a in kw})
         return fit_reference(x, init, want_values=want_values, **{a: kw[a] for a in ("max_iter", "tol") if a in kw})
     model, vals = DeviceKMeans(x, init, group=group, **kw).fit(want_values=want_values)

@@ -59,29 +59,32 @@ def get_train_and_test_dataset(folder: str = "data/mnist") -> Tuple[LeNetDataset
 
 def run_experiment_with_lenet300100(train_epochs: int, prune_train_epochs: int, semi_prune_train_epochs: int,
                                     maximum_centroid_bits: int, k_means_initialization_mode: str,
-                                    with_cumulative_weight_distribution: bool, experiment_name: str) -> None:
+                                    with_cumulative_weight_distribution: bool, experiment_name: str,
+                                    *, arith: str = "auto", reloc: str = "auto") -> None:
+    """The reference's entry point and arguments (main.py:31-39); ``arith`` / ``reloc``: Trainer.quantize."""
     reset_seed()
     train_dataset, test_dataset = get_train_and_test_dataset()
     _run_experiment(LeNet300100Trainer(), train_dataset, test_dataset, train_epochs, prune_train_epochs,
                     semi_prune_train_epochs, maximum_centroid_bits, k_means_initialization_mode,
-                    with_cumulative_weight_distribution, experiment_name)
+                    with_cumulative_weight_distribution, experiment_name, arith=arith, reloc=reloc)
 
 
 def run_experiment_with_lenet5(train_epochs: int, prune_train_epochs: int, semi_prune_train_epochs: int,
                                maximum_centroid_bits: int, k_means_initialization_mode: str,
-                               with_cumulative_weight_distribution: bool, experiment_name: str) -> None:
+                               with_cumulative_weight_distribution: bool, experiment_name: str,
+                               *, arith: str = "auto", reloc: str = "auto") -> None:
     """The same experiment on LeNet-5 (the reference's README lists it as a TODO): images as (N, 28, 28, 1)."""
     reset_seed()
     train_dataset, test_dataset = get_train_and_test_dataset()
     as_images = lambda d: LeNetDataset(np.asarray(d.input_data).reshape(-1, 28, 28, 1), d.output_data)  # noqa: E731
     _run_experiment(LeNet5Trainer(), as_images(train_dataset), as_images(test_dataset), train_epochs, prune_train_epochs,
                     semi_prune_train_epochs, maximum_centroid_bits, k_means_initialization_mode,
-                    with_cumulative_weight_distribution, experiment_name)
+                    with_cumulative_weight_distribution, experiment_name, arith=arith, reloc=reloc)
 
 
 def _run_experiment(trainer, train_dataset, test_dataset, train_epochs, prune_train_epochs, semi_prune_train_epochs,
                     maximum_centroid_bits, k_means_initialization_mode, with_cumulative_weight_distribution,
-                    experiment_name) -> None:
+                    experiment_name, arith: str = "auto", reloc: str = "auto") -> None:
     report_directory = f"{trainer.model_name}_{experiment_name}"
 
     train_accuracies = trainer.train(train_dataset=train_dataset, test_dataset=test_dataset, epochs=train_epochs)
@@ -92,7 +95,8 @@ def _run_experiment(trainer, train_dataset, test_dataset, train_epochs, prune_tr
     trainer.store_report(report_directory)
     after_quantization_accuracy = trainer.quantize(
         test_dataset=test_dataset, with_cumulative_weight_distribution=with_cumulative_weight_distribution,
-        maximum_centroid_bits=maximum_centroid_bits, k_means_initialization_mode=k_means_initialization_mode)
+        maximum_centroid_bits=maximum_centroid_bits, k_means_initialization_mode=k_means_initialization_mode,
+        arith=arith, reloc=reloc)
 
     pathlib.Path(report_directory).mkdir(parents=True, exist_ok=True)
     with open(f"{report_directory}/accuracies.txt", "w") as f:

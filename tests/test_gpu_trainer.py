@@ -88,6 +88,42 @@ def test_quantize_matches_oracle_layer_by_layer(trainer_mod, bits, mode, with_cd
                 assert len(np.unique(got.cpu().numpy())) <= km.cluster_centers_.size
 
 
+@pytest.mark.parametrize("bits,mode,with_cdf", [(2, "density", True), (4, "linear", False), (5, "density", True), (5, "linear", False)])
+def test_quantize_in_reference_arithmetic_is_the_reference(trainer_mod, gold, bits, mode, with_cdf):
+    """BASELINE configs[0] and [1] through the TRAINER entry (Trainer.quantize, /root/reference/.../common/trainer.py:42-72) with
+    arith="reference", reloc="reference": every tensor of LeNet-300-100 then holds exactly what the reference's
+    get_quantized_weight returned for it (goldens made by the reference itself: the decoded tensor by SHA-256, the centres by
+    value, n_iter_) -- the tie at a relocation cut that sends the default fit of dense1 (linear, 4 bits) to another optimum included.
+    The default arithmetic is timed beside it."""
+    import hashlib
+    import time
+
+    lt, tr, _, _ = trainer_mod
+    test = tr.LeNetDataset(np.random.RandomState(0).rand(64, 784).astype(np.float32), np.zeros(64, dtype=np.int64))
+    took = {}
+    for arith, reloc in (("auto", "auto"), ("reference", "reference")):
+        tr.Trainer.pruned_indexes_by_layer.clear()
+        t = lt.LeNet300100Trainer()
+        _load_synth_weights(t.neural_network)
+        t._prune_parameters(True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t.quantize(test, with_cdf, bits, mode, arith=arith, reloc=reloc)
+        torch.cuda.synchronize()
+        took[arith] = time.perf_counter() - t0
+    for name, _, _ in synth.LENET_300_100:
+        layer = getattr(t.neural_network, name)
+        for kind, got, model in zip("wb", layer.get_weights(), t.quantized_models_by_layer[layer]):
+            c = gold.cases[f"quant/cfg2/l300.{name}.{kind}/{mode}{bits}"]
+            if c["passthrough"]:
+                assert model is None
+                continue
+            assert model.arith_ == "reference" and model.n_iter_ == c["n_iter"], (name, kind, model.n_iter_, c["n_iter"])
+            assert np.array_equal(model.cluster_centers_.ravel(), gold.arr(c["centers"]).ravel()), (name, kind)
+            assert hashlib.sha256(np.ascontiguousarray(got.cpu().numpy()).tobytes()).hexdigest() == c["quantized_sha256"], (name, kind)
+    print(f"LeNet-300-100 {mode}{bits}: Trainer.quantize {took['auto'] * 1e3:.1f} ms (default arithmetic), {took['reference'] * 1e3:.1f} ms (reference arithmetic)")
+
+
 def test_run_experiment_surface(trainer_mod, tmp_path, monkeypatch):
     _, tr, main, _ = trainer_mod
     tr.Trainer.pruned_indexes_by_layer.clear()
