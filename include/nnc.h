@@ -191,7 +191,7 @@ typedef struct nnc_kmeans_params {
     int32_t fix_shift; /* S of the fixed-point sums, from nnc_fix_shift() */
     int32_t grid_log2; /* log2 of the number of cells of the search grid; 0 = library default */
     int32_t replicas_log2; /* log2 of LDS accumulator replicas; -1 = library default */
-    int32_t flags;     /* 0 (the library chooses), NNC_KM_TWO_LAUNCH or NNC_KM_LOOP */
+    int32_t flags;     /* 0 (the library chooses), NNC_KM_TWO_LAUNCH or NNC_KM_LOOP, | NNC_KM_MASS_IN_PLACE */
     float x_mean;      /* NumPy float32 mean of the whole vector */
     float tol;         /* float32(np.var(x)) * float32(1e-4) */
     float lo, hi;      /* min and max of the centred data x - x_mean (float32) */
@@ -209,6 +209,9 @@ typedef struct nnc_kmeans_params {
  * takes 0.44 - 0.64 of the launch-per-iteration time up to K = 32, about the same at K = 65, 1.03 - 1.09 of it at K = 129 and about
  * 1.4 at K = 257). */
 #define NNC_KM_LOOP 2
+#define NNC_KM_MASS_IN_PLACE 4 /* (with the launch-per-iteration form, more than 64 centres) nnc_kmeans_fit lets the finalize step settle MASS
+                               * empty-cluster events itself as well instead of enqueuing the relocation chain "in case": same trajectory;
+                               * measured slower on the bench fit, kept for experiments and covered by tests */
 #define NNC_KM_LOOP_KMAX 64
 
 typedef struct nnc_kmeans_status {

@@ -23,6 +23,7 @@ NNC_CHUNK = 8192
 FOLD_SUM, FOLD_MEAN, FOLD_STD = 0, 1, 2
 NNC_KM_TWO_LAUNCH = 1   # nnc_kmeans_params.flags: iterate launch by launch (include/nnc.h)
 NNC_KM_LOOP = 2         # ... inside one resident workgroup whatever K
+NNC_KM_MASS_IN_PLACE = 4  # ... nnc_kmeans_fit: mass empty-cluster events settled by the finalize step (experiment; include/nnc.h)
 NNC_KM_LOOP_KMAX = 64  # up to here the library takes the loop by itself
 
 

@@ -957,6 +957,7 @@ struct KmWs {
     int32_t kl_stats[8]; // [0] iterations the loop ran, [1] its launches, [2] of them with centres changing places, [3] iterations handed over, [4] iterations the wide pair ran, [5] empty-cluster events the loop settled itself
     unsigned long long kl_keys[KL_RKEYS]; // candidate keys of such an event (kl_relocate)
     int32_t bnd_phi[NNC_KMAX]; // per boundary j of the last k_bounds pass: the highest centre that could still win below U_j (the finalize step labels the undecided samples of an empty-cluster event with it, km_finalize_relocate)
+    unsigned long long kl_mkeys[40960]; // candidate keys of a MASS empty-cluster event settled by the finalize step (kl_relocate_mass, KL_MKEYS)
     float kl_hL[2 * NNC_KMAX], kl_hR[2 * NNC_KMAX]; // per search (two a boundary: its ranks hint_a / hint_b): the threshold the rank was found for, the local density there (samples per unit)
     KmTab tab[2];
 };
@@ -2326,7 +2327,7 @@ __device__ __forceinline__ int km_vote_count(int *word, const int x) // threads 
 // and the rest of a batch gone idle) is then not needed.  Returns 1 when the sums in sum_o / cnt_o have been edited and the step
 // goes on as if resumed; 0 when the event is not one for this path (more than KL_RM_MAX empty clusters, long undecided
 // stretches, no proof, ...): nothing has changed and the step pauses as before.
-template <int NT>
+template <int NT, bool MASS>
 __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restrict__ xs, const long long n, const KmTab *__restrict__ tab, const int ku,
                                     const int k, const int cur, long long *sum_o, long long *cnt_o, const float mean, const int Sft)
 {
@@ -2353,7 +2354,9 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
     for (int j = tid; j < k; j += NT) { e += cnt_o[j] == 0; L.cold[j] = ws->c[cur][j]; }
     if (e) atomicAdd(&hd->n_empty, e);
     __syncthreads();
-    if (hd->n_empty > KL_RM_MAX || 2 * ku > KL_RPASS * (NT / 8)) return 0; // (not an event for this path: leave before the tables are fetched)
+    const bool mass = MASS && hd->n_empty > KL_RM_MAX; // (the first iterations behind a density / forgy init: kl_relocate_mass)
+    if (!MASS && hd->n_empty > KL_RM_MAX) return 0;
+    if (!mass && 2 * ku > KL_RPASS * (NT / 8)) return 0; // (not an event for this path: leave before the tables are fetched)
     for (int p = tid; p < ku; p += NT) {
         const float2 c = tab->cand[p];
         L.cs[p] = c.x; L.csq[p] = c.y; L.so[p] = tab->orig[p];
@@ -2373,7 +2376,7 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
         if (len > 0) {
             const int cs_ = (int)L.phi[j] == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
             const long long nc = (len + cs_ - 1) / cs_;
-            if (nc > 64) hd->slow = 1;
+            if (nc > (mass ? 512 : 64)) hd->slow = 1; // (a mass event's keys live in the workspace: room for a long stretch as well)
             else {
                 const int first = atomicAdd(&hd->nch, (int)nc);
                 qfirst[j] = first;
@@ -2382,7 +2385,18 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
         }
     }
     __syncthreads();
+    if (NNC_FIN_TRACE_PTR && tid == 0) { // diagnostics: what every event of the fit looked like (by iteration)
+        unsigned long long *rt = NNC_FIN_TRACE_PTR;
+        const int it = min(ws->st.iter, 63);
+        rt[300 + 4 * it] = (unsigned long long)hd->n_empty; rt[301 + 4 * it] = (unsigned long long)hd->nch; rt[302 + 4 * it] = (unsigned long long)hd->slow; rt[303 + 4 * it] = (unsigned long long)ku;
+    }
     if (hd->slow || hd->nch > 1024) return 0; // (beyond that the candidate list would not fit anyway: kl_relocate checks)
+    if constexpr (MASS) {
+        if (mass) {
+            __shared__ KlMass mass_s;
+            return kl_relocate_mass<NT>(xs, n, ws, hd, L, &mass_s, sum_o, cnt_o, k, hd->nch, mean, Sft);
+        }
+    }
     return kl_relocate<NT>(xs, n, ws, hd, L, sum_o, cnt_o, k, hd->nch, mean, Sft);
 }
 
@@ -2391,7 +2405,7 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
 // WAVE (NT == 64 only): the body is run by ONE wave of a larger workgroup, so it may not use workgroup barriers; the
 // wave's own lock step (plus a compiler fence) orders its LDS traffic.  Returns true if new zones were left
 // (gcell / hcell / ku_out = {ku, cur} filled), i.e. the cell table has to be rebuilt.
-template <int NT, bool ONEWAVE>
+template <int NT, bool ONEWAVE, bool MASS = false>
 __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out, const bool lazy = false,
                                                  const float *__restrict__ reloc_xs = nullptr, const long long reloc_n = 0)
 {
@@ -2537,11 +2551,11 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         if constexpr (!ONEWAVE) {
             // (the same conditions under which the chain enqueued "in case" goes ahead: km_spec_decide)
             // (n_empty counts THREADS with an empty cluster here: more of them than the selection takes clusters is a mass event)
-            if (n_empty > 0 && n_empty <= KL_RM_MAX && !resume && reloc_xs && mode == FIN_FROM_SHARDS && lazy && !(st_iter >= 1 && same_counts_now)) {
+            if (n_empty > 0 && (MASS || n_empty <= KL_RM_MAX) && !resume && reloc_xs && mode == FIN_FROM_SHARDS && lazy && !(st_iter >= 1 && same_counts_now)) {
                 __syncthreads(); // (the global stores of this step so far are out before the selection reads the workspace)
                 if (ftr && tid == 0) { ftr[20] = ftr[0]; ftr[21] = __builtin_amdgcn_s_memrealtime(); }
                 const KmTab *tabc = &ws->tab[cur];
-                settled = km_finalize_relocate<NT>(ws, reloc_xs, reloc_n, tabc, cur ? ku1 : ku0, k, cur, sum_o, cnt_o, ws->p.x_mean, Sft) != 0;
+                settled = km_finalize_relocate<NT, MASS>(ws, reloc_xs, reloc_n, tabc, cur ? ku1 : ku0, k, cur, sum_o, cnt_o, ws->p.x_mean, Sft) != 0;
                 if (settled) { n_empty = 0; settled_event = true; }
                 if (settled && ftr && tid == 0) ftr[22] = __builtin_amdgcn_s_memrealtime();
             }
@@ -2901,7 +2915,10 @@ __device__ __forceinline__ uint16_t km_cell_entry(int g, int G, int ku, const in
 // runs the body, then all of them turn the zones into the cell table (a few cells per thread) -- no k_cells launch.
 // The last launch of a batch may carry the host's look-in (nnc_kmeans_iterate_publish): once the state is final the
 // status block and the ticket go out here when no k_cells launch follows to carry them.
-template <int NT, bool FUSED>
+// MASS: the body may settle mass empty-cluster events as well (kl_relocate_mass; nnc_kmeans_params.flags & NNC_KM_MASS_IN_PLACE).  A
+// variant of its own: the code is large, and code that runs once a launch arrives cold -- with it in the default kernel the small
+// events the finalize step settles in place went from 41-55 to 59-65 us.
+template <int NT, bool FUSED, bool MASS = false>
 __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume,
                                                                       nnc_kmeans_status *host_st, unsigned long long *host_ticket,
                                                                       unsigned long long ticket, int lazy, const float *__restrict__ reloc_xs,
@@ -2937,7 +2954,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
             if (tid == 0) tab->n_ovf = fin_novf;
         }
     } else {
-        km_finalize_body<NT, false>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n);
+        km_finalize_body<NT, false, MASS>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n);
     }
     if (cond && fin_asked) { // the iteration k_lloyd handed over has been run (or has paused): the loop may go on
         __syncthreads();
@@ -3121,10 +3138,13 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
     nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
 #define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0), reloc_xs, (long long)(p ? p->n : 0))
+#define KM_LAUNCH_FIN_MASS(NT, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, false, true>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0), reloc_xs, (long long)(p ? p->n : 0))
+    const bool mass = p && (p->flags & NNC_KM_MASS_IN_PLACE) && reloc_xs && !fused && k > 64;
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);
-    else if (k > 0 && k <= 256) KM_LAUNCH_FIN(256, false, 256); // (measured at K = 257: one wave 23.6 us, four waves 14.6 / 17.7 us median / mean, sixteen 14.4 / 15.9)
-    else KM_LAUNCH_FIN(KM_THREADS, false, KM_THREADS);
+    else if (k > 0 && k <= 256) { if (mass) KM_LAUNCH_FIN_MASS(256, 256); else KM_LAUNCH_FIN(256, false, 256); } // (measured at K = 257: one wave 23.6 us, four waves 14.6 / 17.7 us median / mean, sixteen 14.4 / 15.9)
+    else { if (mass) KM_LAUNCH_FIN_MASS(KM_THREADS, KM_THREADS); else KM_LAUNCH_FIN(KM_THREADS, false, KM_THREADS); }
+#undef KM_LAUNCH_FIN_MASS
 #undef KM_LAUNCH_FIN
     LAUNCHCHK("k_finalize");
     if (cells) {
@@ -4952,9 +4972,14 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
     // a batch goes by without one.
     const bool spec_ok = sorted && !one_launch && p.prefix_dev && reloc_scratch_dev && (reinterpret_cast<uintptr_t>(reloc_scratch_dev) & 255) == 0 &&
                          reloc_scratch_bytes >= nnc_kmeans_reloc_scratch_bytes(p.k, KM_SPEC_WMAX) && p.n >= 2 * KM_SPEC_WMAX;
-    bool spec = spec_ok;
-    int batch = one_launch ? p.max_iter : (spec ? 6 : 1); // the first iteration is where duplicate initial centres surface as empty clusters
-                                                           // (six with chains: the mass events come first; small ones need no chain)
+    // Round 4, opt-in (flags & NNC_KM_MASS_IN_PLACE): the finalize step of a launch-per-iteration pass settles mass events itself as well
+    // (kl_relocate_mass) and that form then carries no chain.  Same trajectory; measured on the bench fit it does not pay (12 of 13
+    // events in place, a mass event 92-100 us in the finalize launch against about 95 through the chain: 2.87 ms per step against 2.76),
+    // so the default stays the chain.
+    const bool mass_in_place = (p.flags & NNC_KM_MASS_IN_PLACE) && !lloyd && p.k > 64;
+    bool spec = spec_ok && !mass_in_place;
+    int batch = one_launch ? p.max_iter : (spec_ok ? 6 : 1); // the first iteration is where duplicate initial centres surface as empty clusters
+                                                              // (six with chains: the mass events come first; small ones need no chain)
     if (lloyd) batch = KM_LLOYD_ROUNDS; // rounds per look-in: a round ends at an empty cluster (settled by the chain behind it, if there is one) or a handed-over iteration
     bool first_launch = true;
     int nwin = 0, nrel_seen = status_out->n_relocated, nunp_seen = status_out->n_unproven; // (a call after a full-pass relocation carries on from the last status)

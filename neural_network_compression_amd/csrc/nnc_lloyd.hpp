@@ -913,6 +913,434 @@ __device__ __forceinline__ int kl_relocate(const float *__restrict__ xs, const l
     return hd->r_bad ? 0 : 1;
 }
 
+// ---- the same for a MASS event (more than KL_RM_MAX empty clusters: the first iterations behind a density / forgy init, whose duplicate
+// centres own nothing) ------------------------------------------------------------------------------------------------------------------
+// kl_relocate finds its m + 1 keys by m + 1 rounds of a workgroup-wide maximum: fine for a handful, hopeless for the 164 / 98 / 54 ...
+// empty clusters of the bench fit's first iterations, which therefore went through the chain of four launches behind the iteration
+// (window table, candidates, selection, resumed finalize: about 85 us with its launch boundaries, seven times a step).  Same candidates,
+// same keys, same proof here, with what a mass event needs:
+//   * the keys go to the workspace (ws->kl_mkeys), not to registers;
+//   * the m largest come from a cut on the distance bits (12 + 12 + 7 bits, refined while more than KL_MS_SMALL keys lie at or above
+//     it) and an exact ranking of the few that survive it -- k_reloc_select's selection, on 64-bit keys;
+//   * windows in two turns: KL_MW1 samples at each end of every certain stretch first (an end may have to supply all m, but the far
+//     samples of a mass event sit at a few ends in the tails); the ends whose innermost candidate is not strictly below the cut --
+//     and only those -- are then read to a depth above m and the selection is repeated over everything.  The cut can only rise when
+//     keys are added, so ends that passed in the first turn pass in the second, and an end read deeper than m cannot hold m + 1 keys
+//     at or above the m-th largest: two turns settle it (equal keys in a crowd at the cut aside, which the ranking refuses);
+//   * the clusters the selected samples leave by one thread per sample; the edits of m clusters by LDS atomics (integers: any order).
+// Returns 1 when the event is settled, 0 when it is not (nothing has changed then: the step pauses and the host's look-in takes it).
+#define KL_MKEYS 40960   // keys of a mass event in the workspace (ws->kl_mkeys): the first turn's 2 * ku * 16 (ku <= 1032) and what joins them
+#define KL_MW1L 4        // log2 of the first turn's window
+#define KL_MS_MAX 2048   // keys at or above the cut that are ranked exactly
+#define KL_MS_SMALL 384  // ... the cut is refined while there are more
+struct KlMass {
+    unsigned hist[4096];
+    unsigned long long surv[KL_MS_MAX];
+    unsigned long long sel[NNC_KMAX + 8];  // the selected keys, descending (one more than there are empty clusters)
+    unsigned innerq[2 * NNC_KMAX];         // per end: distance bits of its innermost candidate if samples lie behind it, else 0
+    uint16_t flist[2 * NNC_KMAX];          // the ends that go into the second turn
+    uint8_t failq[2 * NNC_KMAX];
+    uint16_t empty[NNC_KMAX], old[NNC_KMAX];
+    int leave[NNC_KMAX];
+    int wave_i[16];
+    int cut, above, ge, nsurv, nf, cnt, over;
+    unsigned thr;
+};
+
+// The cut: a threshold thr on the distance bits such that at least m and at most KL_MS_MAX of keys[0 .. N) (zero = no key) lie at or
+// above it; those keys go to M->surv (any order), their number to M->nsurv, thr to M->thr.  0 if there are fewer than m keys or a
+// crowd of more than KL_MS_MAX equal distances sits at the finest cut.
+template <int NT>
+__device__ int kl_mass_cut(const unsigned long long *__restrict__ keys, const int N, const int m, KlMass *M)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned prefix = 0, thr = 0;
+    int pshift = -1, above = 0, total_ge = N;
+    const int shifts[3] = {19, 7, 0}, widths[3] = {12, 12, 7};
+    for (int lvl = 0; lvl < 3; lvl++) {
+        const int shift = shifts[lvl], width = widths[lvl];
+        const unsigned mask = (1u << width) - 1u;
+        for (int i = tid; i < 4096; i += NT) M->hist[i] = 0u;
+        if (tid == 0) { M->cut = 0; M->above = above; M->ge = total_ge; M->nsurv = 0; }
+        __syncthreads();
+        for (int i0 = 0; i0 < N; i0 += 8 * NT) { // (neighbouring keys have similar distances: a wave that lands in one bin adds once)
+            unsigned long long kq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * NT + tid; kq[u] = i < N ? keys[i] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const unsigned uu = (unsigned)(kq[u] >> 32);
+                const bool have = kq[u] != 0ull && (pshift < 0 || (uu >> pshift) == prefix);
+                const unsigned bn = have ? (uu >> shift) & mask : 0xFFFFu;
+                const unsigned long long act = __ballot(have);
+                if (act) {
+                    const unsigned first = (unsigned)__shfl((int)bn, __ffsll((long long)act) - 1);
+                    if (__all(!have || bn == first)) { if (lane == 0) atomicAdd(&M->hist[first], (unsigned)__popcll(act)); }
+                    else if (have) atomicAdd(&M->hist[bn], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // thread t owns bins [t * per, (t + 1) * per); everything in higher bins via a block prefix sum
+        constexpr int per = 4096 / NT > 0 ? 4096 / NT : 1;
+        unsigned hb[per];
+        int own = 0;
+#pragma unroll
+        for (int q = 0; q < per; q++) { hb[q] = (tid * per + q < 4096) ? M->hist[tid * per + q] : 0u; own += (int)hb[q]; }
+        int sc = own;
+        for (int off = 1; off < 64; off <<= 1) { const int t_ = __shfl_up(sc, off); if (lane >= off) sc += t_; }
+        if (lane == 63) M->wave_i[wv] = sc;
+        __syncthreads();
+        int pre = 0, tot = 0;
+        for (int w = 0; w < NT / 64; w++) { const int v = M->wave_i[w]; if (w < wv) pre += v; tot += v; }
+        int run = above + (tot - (pre + sc)); // keys above this thread's bins (and above the prefix)
+        for (int q = per - 1; q >= 0; q--) {
+            const int before = run;
+            run += (int)hb[q];
+            if (before < m && run >= m) { M->cut = tid * per + q; M->above = before; M->ge = run; } // exactly one thread, one bin
+        }
+        __syncthreads();
+        const int bcut = M->cut;
+        prefix = (pshift < 0) ? (unsigned)bcut : ((prefix << width) | (unsigned)bcut);
+        pshift = shift;
+        above = M->above;
+        total_ge = M->ge;
+        thr = prefix << shift;
+        __syncthreads();
+        if (total_ge <= KL_MS_SMALL) break;
+    }
+    if (total_ge > KL_MS_MAX || total_ge < m) return 0; // a crowd of equal distances at the cut / fewer keys than empty clusters
+    for (int i0 = 0; i0 < N; i0 += 8 * NT) {
+        unsigned long long kq[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int i = i0 + u * NT + tid; kq[u] = i < N ? keys[i] : 0ull; }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (kq[u] != 0ull && (unsigned)(kq[u] >> 32) >= thr) {
+                const int slot = atomicAdd(&M->nsurv, 1);
+                if (slot < KL_MS_MAX) M->surv[slot] = kq[u];
+            }
+    }
+    if (tid == 0) M->thr = thr;
+    __syncthreads();
+    return M->nsurv >= m && M->nsurv <= KL_MS_MAX;
+}
+
+// M->surv[0 .. ms) into descending order (every thread walks the list once: the reads are LDS broadcasts), then M->sel[0 .. m] = the
+// first m + 1 of them (0 where there is none: the runner-up shows a tie at the cut)
+template <int NT>
+__device__ void kl_mass_rank(const int ms, const int m, KlMass *M)
+{
+    const int tid = threadIdx.x;
+    constexpr int KPT = (KL_MS_MAX + NT - 1) / NT;
+    unsigned long long mine[KPT];
+    int rk[KPT];
+#pragma unroll
+    for (int q = 0; q < KPT; q++) { const int i = tid + q * NT; mine[q] = i < ms ? M->surv[i] : 0ull; rk[q] = 0; }
+    const int mine_n = (ms - tid + NT - 1) / NT; // keys this thread holds (<= 0: none)
+    if (mine_n > 0) {
+#pragma unroll 4
+        for (int j = 0; j < ms; j++) {
+            const unsigned long long kj = M->surv[j];
+#pragma unroll
+            for (int q = 0; q < KPT; q++) rk[q] += (kj > mine[q]) || (kj == mine[q] && j < tid + q * NT);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < KPT; q++) if (tid + q * NT < ms) M->surv[rk[q]] = mine[q]; // every rank 0 .. ms-1 is taken exactly once
+    __syncthreads();
+    for (int r = tid; r <= m; r += NT) M->sel[r] = (r < ms) ? M->surv[r] : 0ull;
+    __syncthreads();
+}
+
+template <int NT>
+__device__ int kl_relocate_mass(const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws, KlHead *hd, const KlArr &L, KlMass *M,
+                                long long *sumo, long long *cnto, const int k, const int nch, const float mean, const int Sft)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = tid >> 3, gl = tid & 7;
+    const int ku = hd->ku, m = hd->n_empty;
+    if (tid == 0 && m > ws->kl_stats[7]) ws->kl_stats[7] = m;
+    unsigned long long *rtr = NNC_FIN_TRACE_PTR; // diagnostics: phase stamps, ten slots per event of the fit (by the number of events before it)
+    const int ord_ = min(ws->st.n_relocated, 15);
+#define KMSTAMP(i) do { if (rtr && tid == 0) rtr[100 + 10 * ord_ + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    KMSTAMP(0);
+    if (rtr && tid == 0) rtr[100 + 10 * ord_ + 9] = (unsigned long long)m;
+    if (m < 1 || m >= k || hd->r_flat) return 0;
+    int Wl2 = KL_MW1L;
+    while ((1 << Wl2) <= m) Wl2++;                 // second turn: W2 > m
+    const int W1 = 1 << KL_MW1L, W2 = 1 << Wl2;
+    const int n_ends = 2 * ku * W1;
+    unsigned long long *keys = ws->kl_mkeys;
+    for (int i = tid; i < k; i += NT) M->leave[i] = 0;
+    for (int q = tid; q < 2 * ku; q += NT) { M->innerq[q] = 0u; M->failq[q] = 0; }
+    if (tid == 0) { M->over = 0; M->nf = 0; M->cnt = 0; }
+    __syncthreads();
+    // rank of the sample at depth i of end q (-1 if the end has no such sample); the lower end's window reaches W_lo samples up from
+    // the bottom of its stretch, the upper end owns what lies above that; top_held: samples at the top of the stretch that are the
+    // upper end's already (none while the lower end's first window is made, W1 when it is deepened: no sample gets two keys)
+    auto end_rank = [&](int q, int i, int W_lo, int top_held, long long &lo_r, long long &hi_r) -> long long {
+        const int p_ = q >> 1, side = q & 1;
+        lo_r = p_ > 0 ? L.B[p_ - 1] : 0; hi_r = p_ == ku - 1 ? n : L.A[p_];
+        long long r;
+        if (side == 0) { r = lo_r + i; if (r >= hi_r - top_held) r = -1; }
+        else { r = hi_r - 1 - i; if (r < lo_r + W_lo) r = -1; } // (a short stretch: its first W_lo samples are the lower end's)
+        return r;
+    };
+    auto key_of = [&](float xv, float cen) -> unsigned long long {
+        const float dd = (xv - mean) - cen;
+        const float dv = dd * dd;
+        return ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned long long)f32_ordered_bits(xv);
+    };
+    // ---- first turn: W1 samples at each end of every certain stretch, the outermost first
+    for (int s0 = 0; s0 < n_ends; s0 += 8 * NT) { // (eight loads a thread in flight)
+        long long rr[8];
+        float xq[8];
+        bool deep[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sl = s0 + u * NT + tid;
+            rr[u] = -1; deep[u] = false;
+            if (sl < n_ends) {
+                const int q = sl >> KL_MW1L, i = sl & (W1 - 1);
+                long long lo_r, hi_r;
+                rr[u] = end_rank(q, i, W1, 0, lo_r, hi_r);
+                deep[u] = i == W1 - 1 && hi_r - lo_r > 2ll * W1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) xq[u] = rr[u] >= 0 ? xs[rr[u]] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int sl = s0 + u * NT + tid;
+            unsigned long long key = 0ull;
+            if (rr[u] >= 0) {
+                const int q = sl >> KL_MW1L;
+                key = key_of(xq[u], L.cs[q >> 1]);
+                if (deep[u]) M->innerq[q] = (unsigned)(key >> 32);
+            }
+            if (sl < n_ends) keys[sl] = key;
+        }
+    }
+    __syncthreads(); // (also a fence over the keys in the workspace: every thread reads other threads' keys below)
+    KMSTAMP(1); // ends of the certain stretches
+    // ---- the cut over the ends alone: a lower bound of the final cut (more keys can only raise the m-th largest)
+    if (n_ends > KL_MKEYS) { if (tid == 0) ws->kl_stats[6] |= 2; return 0; }
+    unsigned thr = 0u;
+    int Ncut = n_ends;
+  for (int turn = 0;; turn++) { // (ONE call site of the cut: with two the compiler (ROCm 7.2) dies on the LDS pointer it shares between them)
+    if (!kl_mass_cut<NT>(keys, Ncut, m, M)) { if (tid == 0) ws->kl_stats[6] |= 64; return 0; }
+    if (turn == 1) break; // (the cut over everything, made again because many keys joined the survivors of the first one)
+    thr = M->thr;
+    kl_mass_rank<NT>(M->nsurv, m, M);
+    KMSTAMP(2); // first selection
+    // ---- which ends are not deep enough?  (their innermost candidate has samples behind it and is not strictly below the cut)
+    {
+        const unsigned cutb = (unsigned)(M->sel[m - 1] >> 32);
+        for (int q = tid; q < 2 * ku; q += NT)
+            if (M->innerq[q] != 0u && M->innerq[q] >= cutb) { M->failq[q] = 1; M->flist[atomicAdd(&M->nf, 1)] = (uint16_t)q; }
+    }
+    __syncthreads();
+    const int nf = M->nf;
+    if (rtr && tid == 0) rtr[100 + 10 * ord_ + 8] = ((unsigned long long)n_ends << 32) | (unsigned long long)nf;
+    // whatever is found from here on joins the survivors if it lies at or above the first threshold (nothing below it can be among
+    // the m largest of the larger set)
+    // (they are also appended to the keys in the workspace: should the survivors become many -- a coarse first threshold --, the cut
+    // is made again over everything instead of ranking a crowd)
+    auto add_surv = [&](unsigned long long key) {
+        if (key != 0ull && (unsigned)(key >> 32) >= thr) {
+            const int at = n_ends + atomicAdd(&M->cnt, 1);
+            if (at < KL_MKEYS) keys[at] = key;
+            if (at >= KL_MKEYS) atomicOr(&M->over, 1); // (an atomic: the compiler folds a plain LDS store and the global store above into one flat store and trips over it)
+            const int slot = atomicAdd(&M->nsurv, 1);
+            if (slot < KL_MS_MAX) M->surv[slot] = key;
+        }
+    };
+    if (nf > 0) {
+        // ---- second turn: those ends to a depth above m
+        if (W2 <= W1) { if (tid == 0) ws->kl_stats[6] |= 16; return 0; } // (W1 > m already: more than m keys at or above the m-th largest -- a crowd of equal ones)
+        const int extra = W2 - W1;
+        const int n2 = nf * extra;
+        for (int s0 = 0; s0 < n2; s0 += 8 * NT) {
+            long long rr[8];
+            float xq[8];
+            bool deep[8];
+            int qq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int sl = s0 + u * NT + tid;
+                rr[u] = -1; deep[u] = false; qq[u] = 0;
+                if (sl < n2) {
+                    const int f = sl / extra, i = W1 + sl % extra;
+                    const int q = (int)M->flist[f];
+                    qq[u] = q;
+                    const int W_lo = M->failq[q & ~1] ? W2 : W1; // how far the lower end of this stretch reaches now
+                    const int W_up = M->failq[q | 1] ? W2 : W1;
+                    long long lo_r, hi_r;
+                    rr[u] = end_rank(q, i, W_lo, W1, lo_r, hi_r);
+                    deep[u] = i == W2 - 1 && hi_r - lo_r > (long long)W_lo + W_up;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) xq[u] = rr[u] >= 0 ? xs[rr[u]] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (rr[u] >= 0) {
+                    const unsigned long long key = key_of(xq[u], L.cs[qq[u] >> 1]);
+                    if (deep[u]) M->innerq[qq[u]] = (unsigned)(key >> 32); // (the end's innermost candidate is this one now)
+                    add_surv(key);
+                }
+            }
+        }
+        // (an end of the second turn with nothing left behind its window is read to its end)
+        for (int f = tid; f < nf; f += NT) {
+            const int q = (int)M->flist[f];
+            long long lo_r, hi_r;
+            const int W_lo = M->failq[q & ~1] ? W2 : W1, W_up = M->failq[q | 1] ? W2 : W1;
+            (void)end_rank(q, 0, W_lo, 0, lo_r, hi_r);
+            if (!(hi_r - lo_r > (long long)W_lo + W_up)) M->innerq[q] = 0u;
+        }
+        if (tid == 0) ws->kl_stats[6] |= 128; // (diagnostics: an event that took the second turn)
+    }
+    KMSTAMP(3); // second turn
+    // ---- the undecided stretches, chunk by chunk as kl_label went through them.  A sample's key is the distance to ITS centre, one of
+    // the candidates j .. phi of its stretch, so it is at most the distance to the farther of the two outermost candidates: only
+    // samples for which that bound reaches the threshold get the exact label (after a mass relocation thousands of samples sit
+    // between crowded centres -- a loop over dozens of candidates each -- and next to none of them is far from its centre)
+    const int *qfirst = reinterpret_cast<const int *>(L.call);
+    for (int c = g; c < nch; c += NT / 8) {
+        const int j = (int)L.qj[c];
+        const long long bm = j > 0 ? L.B[j - 1] : 0, a = L.A[j], e = L.B[j];
+        const long long s = a > bm ? a : bm;
+        const int phi = L.phi[j];
+        const int cs_ = phi == j + 1 ? KL_CHUNK : KL_CHUNK_CROWD;
+        const long long start = s + (long long)cs_ * (c - qfirst[j]);
+        const long long end = start + cs_ < e ? start + cs_ : e;
+        const float cj = L.cs[j], cp = L.cs[phi];
+        for (long long r0 = start + gl; r0 < end; r0 += 64) { // eight loads a lane in flight
+            float xq[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const long long r = r0 + 8 * u; xq[u] = r < end ? xs[r] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (r0 + 8 * u < end) {
+                    const float xv = xq[u];
+                    const float xc = xv - mean;
+                    const float da = xc - cj, db = xc - cp;
+                    const float ub = fmaxf(da * da, db * db);
+                    if (__float_as_uint(ub) >= thr) {
+                        float bestd = L.csq[j] + (-2.0f * (xc * L.cs[j]));
+                        int best = j, besto = (int)L.so[j];
+                        for (int cc = j + 1; cc <= phi; cc++) {
+                            const float d = L.csq[cc] + (-2.0f * (xc * L.cs[cc]));
+                            const int oc = (int)L.so[cc];
+                            if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = cc; besto = oc; }
+                        }
+                        add_surv(key_of(xv, L.cs[best]));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    KMSTAMP(4); // undecided stretches
+    if (M->over) { if (tid == 0) ws->kl_stats[6] |= 2; return 0; }
+    if (M->nsurv <= KL_MS_SMALL) break;
+    Ncut = n_ends + M->cnt; // many joined: a finer threshold over all keys rather than the ranking of a crowd
+    __syncthreads();
+  }
+    kl_mass_rank<NT>(M->nsurv, m, M);
+    {
+        const unsigned cutb = (unsigned)(M->sel[m - 1] >> 32);
+        int deep_bad = 0;
+        for (int q = tid; q < 2 * ku; q += NT) if (M->innerq[q] != 0u && M->innerq[q] >= cutb) deep_bad = 1;
+        if (__syncthreads_or(deep_bad)) { if (tid == 0) ws->kl_stats[6] |= 16; return 0; }
+    }
+    const unsigned long long kcut = M->sel[m - 1], ktop = M->sel[0];
+    if (kcut == 0ull || (ktop >> 32) == 0ull) { if (tid == 0) ws->kl_stats[6] |= (kcut == 0ull ? 4 : 0) | ((ktop >> 32) == 0ull ? 8 : 0); return 0; } // fewer candidates than empty clusters; every sample on its centre
+    // ---- the empty clusters in ascending order
+    {
+        const int rounds = (k + NT - 1) / NT;
+        int carry = 0;
+        for (int rd = 0; rd < rounds; rd++) {
+            const int j = rd * NT + tid;
+            const int e = (j < k && cnto[j] == 0) ? 1 : 0;
+            const unsigned long long bal = __ballot(e);
+            const int before = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) M->wave_i[wv] = __popcll(bal);
+            __syncthreads();
+            int pre = carry, tot = carry;
+            for (int w = 0; w < NT / 64; w++) { const int c = M->wave_i[w]; if (w < wv) pre += c; tot += c; }
+            if (e && pre + before < NNC_KMAX) M->empty[pre + before] = (uint16_t)j;
+            carry = tot;
+            __syncthreads();
+        }
+    }
+    KMSTAMP(5); // final ranking, proof, list of the empty clusters
+    // ---- the cluster each selected sample leaves: the float32 arg-min over ALL centres, first minimum (km_relocate_apply); a thread a
+    // sample (every thread reads the same centre at the same time: LDS broadcasts, eight in flight)
+    for (int i = tid; i < m; i += NT) {
+        const float xv = f32_from_ordered_bits((unsigned)(M->sel[i] & 0xFFFFFFFFull));
+        const float xc = xv - mean;
+        float best = INFINITY;
+        int old = 0;
+        int j = 0;
+        for (; j + 8 <= k; j += 8) {
+            float cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cv[u] = L.cold[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const float dj = cv[u] * cv[u] + (-2.0f * (xc * cv[u]));
+                if (dj < best) { best = dj; old = j + u; }
+            }
+        }
+        for (; j < k; j++) {
+            const float cv = L.cold[j];
+            const float dj = cv * cv + (-2.0f * (xc * cv));
+            if (dj < best) { best = dj; old = j; }
+        }
+        M->old[i] = (uint16_t)old;
+        atomicAdd(&M->leave[old], 1);
+    }
+    __syncthreads();
+    KMSTAMP(6); // old clusters
+    // no cluster may be left without a sample (scikit-learn does not look again; neither path here tries)
+    int nb = 0;
+    for (int i = tid; i < m; i += NT) { const int o = M->old[i]; if (cnto[o] - M->leave[o] < 1) nb = 1; }
+    if (__syncthreads_or(nb)) { if (tid == 0) ws->kl_stats[6] |= 32; return 0; }
+    // ---- the edits: integers, any order
+    for (int i = tid; i < m; i += NT) {
+        const float xv = f32_from_ordered_bits((unsigned)(M->sel[i] & 0xFFFFFFFFull));
+        const long long v = (long long)fix_f32(xv - mean, Sft);
+        const int old = M->old[i], nw = M->empty[i];
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sumo[old]), (unsigned long long)(-v));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&cnto[old]), (unsigned long long)(-1ll));
+        atomicAdd(reinterpret_cast<unsigned long long *>(&sumo[nw]), (unsigned long long)v);
+        atomicAdd(reinterpret_cast<unsigned long long *>(&cnto[nw]), 1ull);
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) { // (ws->partials: what the relocation kernels edit; partials_local stays as labelled, as there)
+        const int old = M->old[i], nw = M->empty[i];
+        ws->partials[old] = sumo[old]; ws->partials[k + old] = cnto[old];
+        ws->partials[nw] = sumo[nw]; ws->partials[k + nw] = cnto[nw];
+    }
+    if (tid == 0) {
+        // what scikit-learn leaves to numpy.argpartition (km_relocate_apply): the pairing of several, a tie at the cut
+        if (m > 1) ws->st.reloc_multi += 1;
+        const unsigned long long kn = M->sel[m];
+        if (kn != 0ull && (kn >> 32) == (kcut >> 32) && kn != kcut) ws->st.reloc_ties += 1;
+        ws->st.n_relocated += 1; // (the host does not see this event: it counts them from here)
+        ws->st.n_in_place += 1;
+        ws->reloc_fail = 0;
+        ws->kl_stats[5] += 1;
+    }
+    __syncthreads();
+    KMSTAMP(7); // edits
+#undef KMSTAMP
+    return 1;
+}
+
 // ---- the M-step and everything behind it: 0 = go on, 1 = stopped (done), 2 = paused for empty clusters --------------------------
 // second half (from sums and counts in original index order, no cluster empty): _average_centers, _center_shift, the tolerance
 // test, the tables of the new centres

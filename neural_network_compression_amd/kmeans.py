@@ -359,7 +359,7 @@ class DeviceKMeans:
                  batch: int = 16, grid_log2: int = 0, replicas_log2: int = -1, sort: bool | None = None,
                  reloc: str = "auto", stats: LayerStats | None = None, x_sorted: torch.Tensor | None = None,
                  n_total: int | None = None, n_min: int | None = None, comm=None, rank_boundaries: bool = True,
-                 two_launch: bool = False, loop: bool = False):
+                 two_launch: bool = False, loop: bool = False, mass_in_place: bool = False):
         if x.dim() != 1:
             x = x.reshape(-1)
         ops._require_cuda(x, "x", torch.float32)
@@ -411,7 +411,7 @@ class DeviceKMeans:
         self.fix_shift = ops.fix_shift(absmax, n_total)
 
         self.p = nat.KMeansParams(n=n, n_total=n_total, k=self.k, max_iter=int(max_iter), fix_shift=self.fix_shift,
-                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=nat.NNC_KM_TWO_LAUNCH if two_launch else (nat.NNC_KM_LOOP if loop else 0),
+                                  grid_log2=int(grid_log2), replicas_log2=int(replicas_log2), flags=(nat.NNC_KM_TWO_LAUNCH if two_launch else (nat.NNC_KM_LOOP if loop else 0)) | (nat.NNC_KM_MASS_IN_PLACE if mass_in_place else 0),
                                   x_mean=float(mean), tol=float(self.tol_), lo=float(lo), hi=float(hi))
         self.ws_bytes = self.L.nnc_kmeans_workspace_bytes(self.k)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.dev)

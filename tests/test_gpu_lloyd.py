@@ -216,3 +216,36 @@ def test_finalize_step_settles_small_events_itself(km):
                 seen += 1
                 d._relocate_and_resume(st)
         assert seen == b.n_relocations_, (seen, b.n_relocations_)
+
+
+def test_mass_events_settled_by_the_finalize_step_same_trajectory(km):
+    """NNC_KM_MASS_IN_PLACE (opt-in, experiment of round 4): the finalize step of a launch-per-iteration pass settles MASS empty-cluster
+    events itself (kl_relocate_mass: shallow windows at every end, deep ones only where the proof asks, undecided samples by a bound
+    first) instead of the relocation chain.  Density / forgy inits with hundreds of duplicate centres on pruned data: the fit is the
+    default one and the oracle's, bit for bit, event for event -- and the events really were settled in the launch."""
+    import ctypes
+
+    settled = events = 0
+    for n, k, mode, seed in [(2_000_000, 257, "density", 1), (900_000, 257, "forgy", 2), (600_000, 300, "forgy", 3), (1_500_000, 129, "density", 4),
+                             (400_000, 1025, "density", 5)]:
+        x = _pruned(n, 700 + seed)
+        if mode == "density":
+            flat = x[x != 0]
+            init = np.asarray(orc.init_space(x, {129: 7, 257: 8, 1025: 10}[k], "density", orc.get_weight_distribution(flat)), dtype=np.float32)
+        else:
+            init = _init(x, k, "forgy", seed)
+        t = torch.from_numpy(x).cuda()
+        a_km = km.DeviceKMeans(t, init, two_launch=True, mass_in_place=True)
+        a, av = a_km.fit()
+        b, bv = km.DeviceKMeans(t, init, two_launch=True).fit()
+        assert (a.n_iter_, a.n_relocations_, a.stop_reason_) == (b.n_iter_, b.n_relocations_, b.stop_reason_), (n, k, mode)
+        assert (a.reloc_tie_, a.n_reloc_multi_) == (b.reloc_tie_, b.n_reloc_multi_), (n, k, mode)
+        assert np.array_equal(a.cluster_centers_.view(np.uint32), b.cluster_centers_.view(np.uint32)), (n, k, mode)
+        assert np.array_equal(a.labels_, b.labels_) and torch.equal(av, bv)
+        ob = orc.kmeans_lloyd(x, init, accum="B")
+        assert a.n_iter_ == ob.n_iter_ and np.array_equal(a.cluster_centers_.ravel(), ob.cluster_centers_.ravel()), (n, k, mode)
+        st = a_km.loop_stats()
+        settled += st["relocated_in_loop"]
+        events += a.n_relocations_
+        assert a.n_reloc_multi_ >= 1, (n, k, mode)      # there were events of several clusters
+    assert events >= 10 and settled >= events // 2, (events, settled)
