@@ -523,7 +523,7 @@ def main():
         # WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes), if this round's summary is in the tree: a number measured in
         # another run of the same command, labelled as such -- bench.py itself cannot read the counters
         traffic, traffic_source = None, None
-        for cand in ("r03_pmc_hbm_summary.json",):
+        for cand in ("r04_pmc_hbm_summary.json", "r03_pmc_hbm_summary.json"):
             tr_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(tr_path):
                 try:
@@ -531,6 +531,8 @@ def main():
                     traffic_source = f"profiles/{cand}: separate rocprofv3 --pmc passes over `python bench.py --steps 3 --warmup 1`, not this run"
                 except Exception:
                     traffic = None
+                if traffic is not None:
+                    break
         lab = kernels.get("k_assign<labels>", {})
         out = {
             "metric": "weights/sec through prune+k-means (K=256)",
@@ -563,8 +565,14 @@ def main():
                 "frac": lab.get("frac_of_hbm_peak"),
                 "traffic": traffic, "traffic_source": traffic_source,
                 "avg_kernel_ms": lab.get("avg_ms"), "launches_timed": int((all_tags == 2).sum()),
-                "timing": "HIP events around the launch, inside the timed region (rocprofv3 --kernel-trace of the same command: profiles/r03_bench_kernel_stats.csv)",
+                "timing": "HIP events around the launch, inside the timed region (rocprofv3 --kernel-trace of the same command: profiles/r04_bench_kernel_stats.csv)",
                 "algorithmic_bytes_per_launch": lab.get("algorithmic_bytes_per_launch"),
+                # the same launch by SURVEY 8(d)'s literal accounting (the 4 B READ per weight only; the index and the decoded value it also
+                # writes not counted): what "HBM-read roofline on the assignment" means if the writes are left out
+                "frac_read_only_4B": (4.0 * n_loc / (lab["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if lab.get("avg_ms") else None,
+                "accounting": "achieved / frac count the 10 B a weight this launch really moves (4 B read + 2 B index + 4 B value; counter traffic 1.00 x that); "
+                              "frac_read_only_4B counts the 4 B read alone.  In the step the vector comes from HBM (2 ms of other traffic lie between its last use "
+                              "and this launch); launched back to back on data the Infinity Cache still holds the same kernel takes 39.5 us = 0.79 (tools/time_assign.py)",
             },
             "kernels": kernels,
         }

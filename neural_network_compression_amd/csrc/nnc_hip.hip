@@ -1271,7 +1271,11 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     auto step_of = [&](int64_t kk) -> int64_t { return DEAL ? (kk == 0 ? dealt : s0 + kk - 1) : s0 + kk; };
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     const float4 *base = x4 + threadIdx.x;
+#ifdef KM_NT_LOADS // (tuning experiment: the vector is read once per launch)
+    auto ld = [&](int64_t kk) -> float4 { return kk < count ? __builtin_nontemporal_load(&base[step_of(kk) * KM_THREADS]) : make_float4(0.f, 0.f, 0.f, 0.f); };
+#else
     auto ld = [&](int64_t kk) -> float4 { return kk < count ? base[step_of(kk) * KM_THREADS] : make_float4(0.f, 0.f, 0.f, 0.f); };
+#endif
     float4 r[KM_RING];
 #pragma unroll
     for (int j = 0; j < KM_RING; j++) r[j] = ld(j);
@@ -1284,7 +1288,11 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
     const int kp = (k + 7) & ~7;
     const int t = ws->cur ^ (which & 1);
     const KmTab *__restrict__ tab = &ws->tab[t];
+#ifdef KM_KU_FAST // (tuning experiment: one dependent round of loads less at the head; valid for the current table only)
+    const int kt = (which & 1) ? tab->ku : ws->ku_cur;
+#else
     const int kt = tab->ku; // distinct centres: the sorted tables hold only those
+#endif
 
     uint16_t *cell_s = reinterpret_cast<uint16_t *>(smem);
     float4 *pair_s = reinterpret_cast<float4 *>(smem + ((size_t)2 << glog2));

@@ -7,8 +7,9 @@ out=$PWD/gpurun_out/profiles
 rm -rf $out; mkdir -p $out
 CMD="python bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 python bench.py --steps 10 --warmup 2 > $out/bench_plain.json 2> $out/bench_plain.err
-python bench.py --steps 10 --warmup 2 --loop --no-cpu-baseline --no-streaming-leg > $out/bench_loop.json 2> $out/bench_loop.err
-NNC_DIAG=1 python tools/fit_only.py > $out/lloyd_phase_table_k257.txt 2>&1
+python bench.py --config 4 --steps 10 --warmup 3 > $out/bench_config4.json 2> $out/bench_config4.err
+python tools/time_sort.py > $out/sort_times.txt 2>&1
+python tools/time_assign.py > $out/assign_times.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $CMD > $out/bench_under_trace.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -- $CMD > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -- $CMD > /dev/null 2>&1
@@ -49,7 +50,14 @@ def hbm(prefix):
     # gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream -> x2 (MI355X_MICROARCH.md, HBM)
     return 2.0 * s["FETCH_SIZE_KB_mean"] * 1024 + s.get("WRITE_SIZE_KB_mean", 0.0) * 1024
 traffic = hbm("k_assign<1")
+def raw(prefix):
+    ks = [k for k in summ if prefix in k]
+    return None if not ks else {"launches": summ[ks[0]]["launches"], "FETCH_SIZE_bytes": summ[ks[0]]["FETCH_SIZE_KB_mean"] * 1024, "WRITE_SIZE_bytes": summ[ks[0]].get("WRITE_SIZE_KB_mean", 0.0) * 1024}
 json.dump({"k_assign_labels_hbm_bytes_per_launch": traffic,
+           "sort_kernels_raw_counters": {"k_os_prep<true>": raw("k_os_prep<true"), "k_os_pass<9, 0, 0>": raw("k_os_pass<9, 0, 0"), "k_os_pass<9, 0, 1>": raw("k_os_pass<9, 0, 1"),
+                                         "note": "bench vector: 25 M weights, 8 035 375 keys. Algorithmic bytes: prep 100.0 MB read + 32.1 MB keys written; a key pass 32.1 MB read + 32.1 MB written; "
+                                                 "the last pass 32.1 MB read + 100.0 MB written (the values and the block of zeros). FETCH_SIZE counts 64 B per 128-B request for 16 B / lane "
+                                                 "streams (the prep kernel); the passes read one dword a lane, for which the counter is not calibrated (MI355X_MICROARCH.md, HBM)"},
            "k_assign_accumulate_hbm_bytes_per_launch": hbm("k_assign<0"),
            "k_bounds_hbm_bytes_per_launch": hbm("k_bounds"),
            "k_threshold_hbm_bytes_per_launch": hbm("k_threshold"),
@@ -61,3 +69,4 @@ print("traffic", traffic)
 PY
 head -12 $out/bench_kernel_stats.csv | cut -c1-200
 cat $out/bench_plain.json | cut -c1-600
+rm -rf $out/trace $out/pmc_fetch $out/pmc_write
