@@ -15,7 +15,8 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 DIAG = os.environ.get("NNC_DIAG", "0") not in ("", "0")   # diagnostics build (phase traces, ablated kernels): tools/ only
 LIB = os.path.join(CSRC, "libnnc_hip_diag.so" if DIAG else "libnnc_hip.so")
-SOURCES = [os.path.join(CSRC, "nnc_hip.hip"), os.path.join(CSRC, "nnc_sort.hip"), os.path.join(CSRC, "nnc_pp.hip"), os.path.join(CSRC, "nnc_codec.hip"), os.path.join(CSRC, "nnc_layer.hip")]
+SOURCES = [os.path.join(CSRC, f) for f in ("nnc_hip.hip", "nnc_core.hip", "nnc_reduce.hip", "nnc_reffit.hip", "nnc_huffman.hip", "nnc_comm.hip", "nnc_sort.hip", "nnc_pp.hip",
+                                            "nnc_codec.hip", "nnc_layer.hip")]   # (the longest unit first: the units compile side by side)
 EXTRA_LIBS: list = []
 
 

@@ -8,866 +8,8 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared  (see build.py).
 // -ffp-contract=off is REQUIRED: mask bits and centroid indices must reproduce the
 // reference's unfused float32 arithmetic (NumPy / scikit-learn on x86).
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <mutex>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <queue>
-#include <string>
-#include <vector>
-
-#include "nnc.h"
-
-// --------------------------------------------------------------------------------------
-// error plumbing
-// --------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static int fail(int code, const std::string &msg)
-{
-    g_err = msg;
-    return code;
-}
-
-#define HIPCHK(expr)                                                                       \
-    do {                                                                                   \
-        hipError_t e_ = (expr);                                                            \
-        if (e_ != hipSuccess)                                                              \
-            return fail(NNC_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
-    } while (0)
-
-#define LAUNCHCHK(name)                                                                    \
-    do {                                                                                   \
-        hipError_t e_ = hipGetLastError();                                                 \
-        if (e_ != hipSuccess)                                                              \
-            return fail(NNC_EHIP, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
-    } while (0)
-
-int nnc_set_error_(int code, const char *msg) { return fail(code, msg ? msg : ""); } // for the other translation units
-
-extern "C" int nnc_version(void) { return NNC_VERSION; }
-extern "C" const char *nnc_last_error(void) { return g_err.c_str(); }
-
-// Per-device caches (a process may drive several GPUs, from several host threads): indexed by the current device, the
-// entries only ever go from "unknown" to the one value every thread would compute, so plain atomics suffice.
-#define NNC_MAX_DEVICES 64
-static int current_device()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NNC_MAX_DEVICES) dev = 0;
-    return dev;
-}
-static std::atomic<int> g_cu_count[NNC_MAX_DEVICES];
-static int cu_count()
-{
-    const int dev = current_device();
-    int c = g_cu_count[dev].load(std::memory_order_relaxed);
-    if (c == 0) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
-        if (c <= 0) c = 256;
-        g_cu_count[dev].store(c, std::memory_order_relaxed);
-    }
-    return c;
-}
-
-extern "C" int nnc_device_info(char *arch_out, size_t arch_len, int *cu_count_out)
-{
-    int dev = 0;
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDevice(&dev));
-    HIPCHK(hipGetDeviceProperties(&prop, dev));
-    if (arch_out && arch_len) {
-        std::snprintf(arch_out, arch_len, "%s", prop.gcnArchName);
-    }
-    if (cu_count_out) *cu_count_out = prop.multiProcessorCount;
-    return NNC_OK;
-}
-
-static inline hipStream_t S(void *stream) { return reinterpret_cast<hipStream_t>(stream); }
-
-// --------------------------------------------------------------------------------------
-// optional in-library profiler: HIP events around the launches of the data-touching kernels, on the
-// stream each kernel is launched on (hipExtLaunchKernelGGL stamps the events at the kernel's own begin
-// and end, not at the command processor's arrival, so the difference is the launch's execution time).
-// bench.py turns it on to report per-kernel durations over the timed region.
-// --------------------------------------------------------------------------------------
-struct ProfRec { hipEvent_t a, b; int tag; };
-static std::mutex g_prof_mu;            // the pool is shared by every calling thread
-static std::vector<ProfRec> g_prof_pool;
-static size_t g_prof_used = 0;
-static std::atomic<bool> g_prof_on{false};
-static std::atomic<uint32_t> g_prof_mask{0xFFFFFFFFu}; // which NNC_PROF_* tags get events (an event pair costs its launch a little)
-static int64_t g_prof_skipped = 0;
-
-extern "C" int nnc_profile_tags(uint32_t mask) { g_prof_mask = mask; return NNC_OK; }
-
-static void prof_take(int tag, hipEvent_t *a, hipEvent_t *b)
-{
-    *a = nullptr; *b = nullptr;
-    if (!g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> tag) & 1u)) return;
-    std::lock_guard<std::mutex> lock(g_prof_mu);
-    if (g_prof_on && g_prof_used < g_prof_pool.size()) { ProfRec &r = g_prof_pool[g_prof_used++]; r.tag = tag; *a = r.a; *b = r.b; }
-    else g_prof_skipped++;
-}
-#define NNC_LAUNCH_PROF(tag, kernel, grid, block, lds, stream, ...)                                   \
-    do {                                                                                               \
-        hipEvent_t ea_, eb_;                                                                           \
-        prof_take(tag, &ea_, &eb_);                                                                    \
-        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ea_, eb_, 0, __VA_ARGS__);             \
-    } while (0)
-
-extern "C" int nnc_profile_begin(int32_t max_launches)
-{
-    if (max_launches < 1) return fail(NNC_EINVAL, "nnc_profile_begin: max_launches < 1");
-    std::lock_guard<std::mutex> lock(g_prof_mu);
-    while ((int64_t)g_prof_pool.size() < max_launches) {
-        ProfRec pr;
-        pr.tag = -1;
-        HIPCHK(hipEventCreate(&pr.a));
-        HIPCHK(hipEventCreate(&pr.b));
-        g_prof_pool.push_back(pr);
-    }
-    g_prof_used = 0;
-    g_prof_skipped = 0;
-    g_prof_on = true;
-    return NNC_OK;
-}
-
-// Waits for the recorded events and copies the duration (ms) and the NNC_PROF_* tag of each timed launch, in launch
-// order, into ms_out / tags_out[0..cap); count_out = number of launches timed.
-extern "C" int nnc_profile_end(float *ms_out, int32_t *tags_out, int64_t cap, int64_t *count_out)
-{
-    g_prof_on = false;
-    std::lock_guard<std::mutex> lock(g_prof_mu);
-    int64_t cnt = 0;
-    for (size_t i = 0; i < g_prof_used; i++) {
-        HIPCHK(hipEventSynchronize(g_prof_pool[i].b));
-        float ms = 0.0f;
-        HIPCHK(hipEventElapsedTime(&ms, g_prof_pool[i].a, g_prof_pool[i].b));
-        if (ms_out && cnt < cap) ms_out[cnt] = ms;
-        if (tags_out && cnt < cap) tags_out[cnt] = g_prof_pool[i].tag;
-        cnt++;
-    }
-    if (count_out) *count_out = cnt;
-    g_prof_used = 0;
-    return NNC_OK;
-}
-
-
-// --------------------------------------------------------------------------------------
-// small device helpers
-// --------------------------------------------------------------------------------------
-#define WAVE 64
-
-__device__ __forceinline__ void wave_lds_fence()
-{
-    // LDS traffic of one wave executes in order; this only stops the compiler from moving
-    // LDS reads across LDS writes of other lanes of the same wave.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ======================================================================================
-// 1. NumPy-exact float32 reductions
-//
-// np.add.reduce over float32 walks the array in 8192-element buffered chunks; each chunk is
-// summed by the pairwise routine: blocks of <=128 elements with 8 strided accumulators
-// combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), blocks merged as a binary tree (split at
-// n/2 rounded down to a multiple of 8); the chunk sums are folded left to right.  A full
-// 8192 chunk is a perfectly balanced tree of 64 leaves, which maps onto a wave:
-//   * 8 leaves (1024 elements, 4 KiB) per step, loaded as coalesced float4 and transposed
-//     through LDS (leaf stride padded to 136 floats: conflict-free column reads);
-//   * lane (leaf b, accumulator j) adds its 16 elements sequentially;
-//   * xor-shuffles 1,2,4 build the leaf, 8,16,32 the 1024-element node (IEEE addition is
-//     commutative, so both partners of a butterfly hold the same bits);
-//   * the 8 step nodes are merged in registers as a balanced tree.
-// ======================================================================================
-#define LEAF 128
-#define LEAF_PAD 136
-#define STEP_ELEMS 1024
-
-template <bool SQDEV>
-__device__ __forceinline__ float4 xform4(float4 v, float mean)
-{
-    if (SQDEV) {
-        float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
-        v.x = a * a; v.y = b * b; v.z = c * c; v.w = d * d;
-    }
-    return v;
-}
-
-template <bool SQDEV>
-__device__ __forceinline__ float xform1(float v, float mean)
-{
-    if (SQDEV) { float a = v - mean; return a * a; }
-    return v;
-}
-
-// The ragged last chunk (m < 8192 elements): the generic workgroup-parallel pairwise sum.
-struct PwFrame { int start, len, stage; float left; };
-struct PwHeap { int start[256]; int len[256]; float val[256]; };
-template <bool WAVE_ONLY = false, typename F> __device__ float block_pairwise_sum(F elem, int n, PwHeap *hp);
-
-// one wave per full chunk; 4 waves (4 chunks) per workgroup; with a ragged last chunk the grid has one more
-// workgroup, which sums it (so that it runs beside the others instead of in a launch of its own)
-template <bool SQDEV, bool VEC>
-__global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x, int64_t nfull,
-                                                    const float *__restrict__ mean_dev,
-                                                    float *__restrict__ out, int tail)
-{
-    __shared__ __align__(16) float lds[4][8 * LEAF_PAD];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *my = lds[wave];
-    const float mean = SQDEV ? *mean_dev : 0.0f;
-    const int64_t gmain = (int64_t)gridDim.x - (tail > 0 ? 1 : 0); // workgroups that take full chunks
-    if (tail > 0 && blockIdx.x == gridDim.x - 1) {
-        __shared__ PwHeap heap;
-        const float *xt = x + nfull * NNC_CHUNK;
-        const float r = block_pairwise_sum([&](int i) { return xform1<SQDEV>(xt[i], mean); }, tail, &heap);
-        if (threadIdx.x == 0) out[nfull] = r;
-        return;
-    }
-    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nfull; chunk += gmain * 4) {
-        const float *base = x + chunk * NNC_CHUNK;
-        float node[8];
-        float4 cur[4], nxt[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (VEC) cur[r] = reinterpret_cast<const float4 *>(base)[lane + 64 * r];
-            else {
-                const float *p = base + 4 * (lane + 64 * r);
-                cur[r] = make_float4(p[0], p[1], p[2], p[3]);
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            if (it < 7) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (VEC) nxt[r] = reinterpret_cast<const float4 *>(base + (it + 1) * STEP_ELEMS)[lane + 64 * r];
-                    else {
-                        const float *p = base + (it + 1) * STEP_ELEMS + 4 * (lane + 64 * r);
-                        nxt[r] = make_float4(p[0], p[1], p[2], p[3]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int e = 4 * (lane + 64 * r); // element index inside the 1024-element step
-                int b = e >> 7, pos = e & 127;
-                *reinterpret_cast<float4 *>(&my[b * LEAF_PAD + pos]) = xform4<SQDEV>(cur[r], mean);
-            }
-            wave_lds_fence();
-            const float *lp = &my[(lane >> 3) * LEAF_PAD + (lane & 7)];
-            float acc = lp[0];
-#pragma unroll
-            for (int t = 1; t < 16; t++) acc = acc + lp[8 * t];
-            wave_lds_fence();
-            acc = acc + __shfl_xor(acc, 1);
-            acc = acc + __shfl_xor(acc, 2);
-            acc = acc + __shfl_xor(acc, 4);
-            acc = acc + __shfl_xor(acc, 8);
-            acc = acc + __shfl_xor(acc, 16);
-            acc = acc + __shfl_xor(acc, 32);
-            node[it] = acc;
-#pragma unroll
-            for (int r = 0; r < 4; r++) cur[r] = nxt[r];
-        }
-        float s = ((node[0] + node[1]) + (node[2] + node[3])) + ((node[4] + node[5]) + (node[6] + node[7]));
-        if (lane == 0) out[chunk] = s;
-    }
-}
-
-extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const float *mean_dev,
-                                  float *chunk_out, void *stream)
-{
-    if (n < 0 || (n > 0 && (!x || !chunk_out))) return fail(NNC_EINVAL, "nnc_chunk_sums_f32: null pointer");
-    if (sqdev && !mean_dev) return fail(NNC_EINVAL, "nnc_chunk_sums_f32: sqdev needs mean_dev");
-    if (n == 0) return NNC_OK;
-    const int64_t nfull = n / NNC_CHUNK;
-    const int tail = (int)(n % NNC_CHUNK);
-    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    {
-        int64_t blocks = (nfull + 3) / 4;
-        int64_t cap = (int64_t)cu_count() * 8;
-        int grid = (int)std::min<int64_t>(blocks, cap) + (tail > 0 ? 1 : 0);
-        if (sqdev) {
-            if (vec) NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
-            else NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<true, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
-        } else {
-            if (vec) NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<false, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
-            else NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<false, false>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
-        }
-        LAUNCHCHK("k_chunk_sums");
-    }
-    return NNC_OK;
-}
-
-// Sequential float32 fold of the chunk sums (NumPy's order).  The chain of dependent adds is the
-// whole cost (one add per chunk sum, nothing to parallelise); one lane runs it out of LDS with
-// 16-byte reads issued well ahead, the others stage the next tile.
-#define FOLD_TILE 8192
-__global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks, int64_t nchunks, int64_t count,
-                                               int op, const float *__restrict__ scale_dev,
-                                               float *__restrict__ out)
-{
-    __shared__ __align__(16) float buf[FOLD_TILE];
-    float acc = 0.0f;
-    for (int64_t base = 0; base < nchunks; base += FOLD_TILE) {
-        int len = (int)((nchunks - base) < FOLD_TILE ? (nchunks - base) : FOLD_TILE);
-        for (int i = threadIdx.x; i < len; i += 1024) buf[i] = chunks[base + i];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float4 *b4 = reinterpret_cast<const float4 *>(buf);
-            const int nq = len >> 2;
-            int qd = 0;
-            for (; qd + 8 <= nq; qd += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) v[u] = b4[qd + u];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { acc = acc + v[u].x; acc = acc + v[u].y; acc = acc + v[u].z; acc = acc + v[u].w; }
-            }
-            for (; qd < nq; qd++) { const float4 v = b4[qd]; acc = acc + v.x; acc = acc + v.y; acc = acc + v.z; acc = acc + v.w; }
-            for (int i = nq << 2; i < len; i++) acc = acc + buf[i];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        float r = acc;
-        if (op == NNC_FOLD_MEAN || op == NNC_FOLD_STD) r = (float)((double)acc / (double)count);
-        if (op == NNC_FOLD_STD) r = (float)sqrt((double)r); // double sqrt then round == correctly rounded sqrtf
-        out[0] = r;
-        if (scale_dev) out[1] = r * (*scale_dev);
-    }
-}
-
-extern "C" int nnc_fold_f32(const float *chunks, int64_t nchunks, int64_t count, int op, const float *scale_dev,
-                            float *out_dev, void *stream)
-{
-    if (!out_dev || nchunks < 0 || (nchunks > 0 && !chunks)) return fail(NNC_EINVAL, "nnc_fold_f32: bad argument");
-    if ((op == NNC_FOLD_MEAN || op == NNC_FOLD_STD) && count <= 0) return fail(NNC_EINVAL, "nnc_fold_f32: count <= 0");
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(1024), 0, S(stream), chunks, nchunks, count, op, scale_dev, out_dev);
-    LAUNCHCHK("k_fold");
-    return NNC_OK;
-}
-
-// ======================================================================================
-// 2. threshold pass: mask = |x| < thr, zero in place, count
-// ======================================================================================
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_threshold(float *__restrict__ x, int64_t n,
-                                                   const float *__restrict__ thr_dev,
-                                                   uint8_t *__restrict__ mask,
-                                                   unsigned long long *__restrict__ nzeroed)
-{
-    const float thr = *thr_dev;
-    unsigned cnt = 0;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    int64_t done = 0;
-    if (VEC) {
-        const int64_t nvec = n >> 2;
-        float4 *x4 = reinterpret_cast<float4 *>(x);
-        uchar4 *m4 = reinterpret_cast<uchar4 *>(mask);
-        for (int64_t v = tid; v < nvec; v += nthreads) {
-            float4 a = x4[v];
-            uchar4 m;
-            m.x = fabsf(a.x) < thr; m.y = fabsf(a.y) < thr; m.z = fabsf(a.z) < thr; m.w = fabsf(a.w) < thr;
-            cnt += m.x + m.y + m.z + m.w;
-            a.x = m.x ? 0.0f : a.x; a.y = m.y ? 0.0f : a.y; a.z = m.z ? 0.0f : a.z; a.w = m.w ? 0.0f : a.w;
-            x4[v] = a;
-            m4[v] = m;
-        }
-        done = nvec << 2;
-    }
-    for (int64_t i = done + tid; i < n; i += nthreads) {
-        float a = x[i];
-        uint8_t m = fabsf(a) < thr;
-        cnt += m;
-        if (m) x[i] = 0.0f;
-        mask[i] = m;
-    }
-    if (nzeroed) {
-        // same-address global atomics retire one per ~12 ns: one per workgroup, few workgroups
-        __shared__ unsigned wsum[4];
-        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
-        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const unsigned tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-            if (tot) atomicAdd(nzeroed, (unsigned long long)tot);
-        }
-    }
-}
-
-static int stream_grid(int64_t work_items, int threads, int per_cu)
-{
-    int64_t blocks = (work_items + threads - 1) / threads;
-    int64_t cap = (int64_t)cu_count() * per_cu;
-    if (blocks < 1) blocks = 1;
-    return (int)std::min<int64_t>(blocks, cap);
-}
-
-extern "C" int nnc_threshold_mask_f32(float *x, int64_t n, const float *thr_dev, uint8_t *mask,
-                                      int64_t *nzeroed_dev, void *stream)
-{
-    if (n < 0 || !thr_dev || (n > 0 && (!x || !mask))) return fail(NNC_EINVAL, "nnc_threshold_mask_f32: bad argument");
-    if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
-    if (n == 0) return NNC_OK;
-    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
-    int grid = stream_grid((n + 3) / 4, 256, 4);
-    if (vec) NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold<true>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
-    else NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold<false>), dim3(grid), dim3(256), 0, S(stream), x, n, thr_dev, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev));
-    LAUNCHCHK("k_threshold");
-    return NNC_OK;
-}
-
-extern "C" size_t nnc_prune_workspace_bytes(int64_t n)
-{
-    int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
-    return (size_t)(nchunks + 64) * sizeof(float);
-}
-
-__global__ void k_set_thr(float q, float *stats)
-{
-    stats[0] = 0.0f;
-    stats[1] = q;
-}
-__global__ void k_set_f32(float v, float *dst) { *dst = v; }
-
-extern "C" int nnc_prune_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev,
-                             int64_t *nzeroed_dev, void *ws, size_t ws_bytes, void *stream)
-{
-    if (n < 0 || !stats_dev || (n > 0 && (!x || !mask))) return fail(NNC_EINVAL, "nnc_prune_f32: bad argument");
-    if (std_smooth) {
-        if (!ws || ws_bytes < nnc_prune_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_prune_f32: workspace too small");
-        if (n == 0) return fail(NNC_EINVAL, "nnc_prune_f32: std of an empty tensor");
-        float *wsf = reinterpret_cast<float *>(ws);
-        float *scal = wsf;          // [0] mean, [1] q
-        float *chunks = wsf + 16;
-        const int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
-        int rc;
-        hipLaunchKernelGGL(k_set_f32, dim3(1), dim3(1), 0, S(stream), q, scal + 1);
-        LAUNCHCHK("k_set_f32");
-        if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, chunks, stream))) return rc;
-        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_MEAN, nullptr, scal, stream))) return rc;
-        if ((rc = nnc_chunk_sums_f32(x, n, 1, scal, chunks, stream))) return rc;
-        // stats = {sigma, sigma * q}
-        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_STD, scal + 1, stats_dev, stream))) return rc;
-    } else {
-        hipLaunchKernelGGL(k_set_thr, dim3(1), dim3(1), 0, S(stream), q, stats_dev);
-        LAUNCHCHK("k_set_thr");
-    }
-    return nnc_threshold_mask_f32(x, n, stats_dev + 1, mask, nzeroed_dev, stream);
-}
-
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_apply_mask(float *__restrict__ x, const uint8_t *__restrict__ mask, int64_t n)
-{
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    int64_t done = 0;
-    if (VEC) {
-        const int64_t nvec = n >> 2;
-        float4 *x4 = reinterpret_cast<float4 *>(x);
-        const uchar4 *m4 = reinterpret_cast<const uchar4 *>(mask);
-        for (int64_t v = tid; v < nvec; v += nthreads) {
-            uchar4 m = m4[v];
-            if (m.x | m.y | m.z | m.w) {
-                float4 a = x4[v];
-                a.x = m.x ? 0.0f : a.x; a.y = m.y ? 0.0f : a.y; a.z = m.z ? 0.0f : a.z; a.w = m.w ? 0.0f : a.w;
-                x4[v] = a;
-            }
-        }
-        done = nvec << 2;
-    }
-    for (int64_t i = done + tid; i < n; i += nthreads)
-        if (mask[i]) x[i] = 0.0f;
-}
-
-extern "C" int nnc_apply_mask_f32(float *x, const uint8_t *mask, int64_t n, void *stream)
-{
-    if (n < 0 || (n > 0 && (!x || !mask))) return fail(NNC_EINVAL, "nnc_apply_mask_f32: bad argument");
-    if (n == 0) return NNC_OK;
-    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
-    int grid = stream_grid((n + 3) / 4, 256, 16);
-    if (vec) hipLaunchKernelGGL((k_apply_mask<true>), dim3(grid), dim3(256), 0, S(stream), x, mask, n);
-    else hipLaunchKernelGGL((k_apply_mask<false>), dim3(grid), dim3(256), 0, S(stream), x, mask, n);
-    LAUNCHCHK("k_apply_mask");
-    return NNC_OK;
-}
-
-// ======================================================================================
-// 3. min / max / count, 31-bin histogram, bincount
-// ======================================================================================
-struct MinMaxPartial { float mn, mx; unsigned long long cnt; unsigned long long neg, zer; float mn_nz, mx_nz; };
-
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_minmax(const float *__restrict__ x, int64_t n, int skip_zeros,
-                                                MinMaxPartial *__restrict__ part)
-{
-    float mn = INFINITY, mx = -INFINITY, mn_nz = INFINITY, mx_nz = -INFINITY;
-    unsigned long long cnt = 0;
-    unsigned neg = 0, zer = 0; // per thread: well below 2^32
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    int64_t done = 0;
-#define MM1(v) do { float v_ = (v); neg += (v_ < 0.0f); const bool z_ = (v_ == 0.0f); zer += z_; if (!z_) { mn_nz = fminf(mn_nz, v_); mx_nz = fmaxf(mx_nz, v_); } \
-        bool use_ = !(skip_zeros && z_); if (use_) { mn = fminf(mn, v_); mx = fmaxf(mx, v_); cnt++; } } while (0)
-    if (VEC) {
-        const int64_t nvec = n >> 2;
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
-        for (int64_t v = tid; v < nvec; v += nthreads) {
-            float4 a = x4[v];
-            MM1(a.x); MM1(a.y); MM1(a.z); MM1(a.w);
-        }
-        done = nvec << 2;
-    }
-    for (int64_t i = done + tid; i < n; i += nthreads) MM1(x[i]);
-#undef MM1
-    unsigned long long negl = neg, zerl = zer;
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_down(mn, off));
-        mx = fmaxf(mx, __shfl_down(mx, off));
-        mn_nz = fminf(mn_nz, __shfl_down(mn_nz, off));
-        mx_nz = fmaxf(mx_nz, __shfl_down(mx_nz, off));
-        cnt += __shfl_down(cnt, off);
-        negl += __shfl_down(negl, off);
-        zerl += __shfl_down(zerl, off);
-    }
-    __shared__ MinMaxPartial sh[4];
-    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = negl; q.zer = zerl; q.mn_nz = mn_nz; q.mx_nz = mx_nz; sh[threadIdx.x >> 6] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        MinMaxPartial p = sh[0];
-        for (int w = 1; w < 4; w++) {
-            p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer;
-            p.mn_nz = fminf(p.mn_nz, sh[w].mn_nz); p.mx_nz = fmaxf(p.mx_nz, sh[w].mx_nz);
-        }
-        part[blockIdx.x] = p;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_minmax_final(const MinMaxPartial *__restrict__ part, int nparts,
-                                                      float *__restrict__ out, long long *__restrict__ count,
-                                                      long long *__restrict__ signs)
-{
-    float mn = INFINITY, mx = -INFINITY, mn_nz = INFINITY, mx_nz = -INFINITY;
-    unsigned long long cnt = 0, neg = 0, zer = 0;
-    for (int i = threadIdx.x; i < nparts; i += 256) {
-        mn = fminf(mn, part[i].mn); mx = fmaxf(mx, part[i].mx); cnt += part[i].cnt; neg += part[i].neg; zer += part[i].zer;
-        mn_nz = fminf(mn_nz, part[i].mn_nz); mx_nz = fmaxf(mx_nz, part[i].mx_nz);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_down(mn, off));
-        mx = fmaxf(mx, __shfl_down(mx, off));
-        mn_nz = fminf(mn_nz, __shfl_down(mn_nz, off));
-        mx_nz = fmaxf(mx_nz, __shfl_down(mx_nz, off));
-        cnt += __shfl_down(cnt, off);
-        neg += __shfl_down(neg, off);
-        zer += __shfl_down(zer, off);
-    }
-    __shared__ MinMaxPartial sh[4];
-    if ((threadIdx.x & 63) == 0) { MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = cnt; q.neg = neg; q.zer = zer; q.mn_nz = mn_nz; q.mx_nz = mx_nz; sh[threadIdx.x >> 6] = q; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        MinMaxPartial p = sh[0];
-        for (int w = 1; w < 4; w++) {
-            p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.cnt += sh[w].cnt; p.neg += sh[w].neg; p.zer += sh[w].zer;
-            p.mn_nz = fminf(p.mn_nz, sh[w].mn_nz); p.mx_nz = fmaxf(p.mx_nz, sh[w].mx_nz);
-        }
-        out[0] = p.mn; out[1] = p.mx;
-        if (count) *count = (long long)p.cnt;
-        if (signs) { signs[0] = (long long)p.neg; signs[1] = (long long)p.zer; out[2] = p.mn_nz; out[3] = p.mx_nz; }
-    }
-}
-
-static int minmax_grid(int64_t n) { return stream_grid((n + 3) / 4, 256, 8); }
-
-extern "C" size_t nnc_minmax_workspace_bytes(int64_t n)
-{
-    (void)n;
-    return (size_t)(cu_count() * 8 + 8) * sizeof(MinMaxPartial);
-}
-
-static int minmax_impl(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev, int64_t *signs_dev,
-                       void *ws, size_t ws_bytes, void *stream)
-{
-    if (n <= 0 || !x || !out_dev || !ws) return fail(NNC_EINVAL, "nnc_minmax_f32: bad argument (n must be > 0)");
-    if (ws_bytes < nnc_minmax_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_minmax_f32: workspace too small");
-    int grid = minmax_grid(n);
-    MinMaxPartial *part = reinterpret_cast<MinMaxPartial *>(ws);
-    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (vec) NNC_LAUNCH_PROF(NNC_PROF_MINMAX, (k_minmax<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
-    else NNC_LAUNCH_PROF(NNC_PROF_MINMAX, (k_minmax<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, part);
-    LAUNCHCHK("k_minmax");
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, out_dev, reinterpret_cast<long long *>(count_dev),
-                       reinterpret_cast<long long *>(signs_dev));
-    LAUNCHCHK("k_minmax_final");
-    return NNC_OK;
-}
-
-extern "C" int nnc_minmax_f32(const float *x, int64_t n, int skip_zeros, float *out_dev, int64_t *count_dev,
-                              void *ws, size_t ws_bytes, void *stream)
-{
-    return minmax_impl(x, n, skip_zeros, out_dev, count_dev, nullptr, ws, ws_bytes, stream);
-}
-
-extern "C" int nnc_minmax_signs_f32(const float *x, int64_t n, float *out_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
-                                    void *stream)
-{
-    if (!signs_dev) return fail(NNC_EINVAL, "nnc_minmax_signs_f32: null signs_dev");
-    return minmax_impl(x, n, 0, out_dev, nullptr, signs_dev, ws, ws_bytes, stream);
-}
-
-// The threshold pass AND the min / max / sign statistics of what it leaves behind, in one pass over the vector: the pruned
-// values are in registers anyway, and the statistics pass that the sort and the k-means set-up need next (nnc_minmax_signs_f32)
-// would read them again.  Same mask, same zeroing, same count as k_threshold; same partials as k_minmax.
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_threshold_stats(float *__restrict__ x, int64_t n, const float *__restrict__ thr_dev,
-                                                         uint8_t *__restrict__ mask, unsigned long long *__restrict__ nzeroed,
-                                                         MinMaxPartial *__restrict__ part)
-{
-    const float thr = *thr_dev;
-    unsigned cnt = 0, neg = 0, zer = 0;
-    float mn = INFINITY, mx = -INFINITY, mn_nz = INFINITY, mx_nz = -INFINITY;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    int64_t done = 0;
-#define TS1(v) do { const float v_ = (v); neg += (v_ < 0.0f); const bool z_ = (v_ == 0.0f); zer += z_; \
-        if (!z_) { mn_nz = fminf(mn_nz, v_); mx_nz = fmaxf(mx_nz, v_); } mn = fminf(mn, v_); mx = fmaxf(mx, v_); } while (0)
-    if (VEC) {
-        const int64_t nvec = n >> 2;
-        float4 *x4 = reinterpret_cast<float4 *>(x);
-        uchar4 *m4 = reinterpret_cast<uchar4 *>(mask);
-        for (int64_t v = tid; v < nvec; v += nthreads) {
-            float4 a = x4[v];
-            uchar4 m;
-            m.x = fabsf(a.x) < thr; m.y = fabsf(a.y) < thr; m.z = fabsf(a.z) < thr; m.w = fabsf(a.w) < thr;
-            cnt += m.x + m.y + m.z + m.w;
-            a.x = m.x ? 0.0f : a.x; a.y = m.y ? 0.0f : a.y; a.z = m.z ? 0.0f : a.z; a.w = m.w ? 0.0f : a.w;
-            x4[v] = a;
-            m4[v] = m;
-            TS1(a.x); TS1(a.y); TS1(a.z); TS1(a.w);
-        }
-        done = nvec << 2;
-    }
-    for (int64_t i = done + tid; i < n; i += nthreads) {
-        float a = x[i];
-        const uint8_t m = fabsf(a) < thr;
-        cnt += m;
-        if (m) { a = 0.0f; x[i] = 0.0f; }
-        mask[i] = m;
-        TS1(a);
-    }
-#undef TS1
-    unsigned long long negl = neg, zerl = zer, cntl = cnt;
-    for (int off = 32; off > 0; off >>= 1) {
-        mn = fminf(mn, __shfl_down(mn, off));
-        mx = fmaxf(mx, __shfl_down(mx, off));
-        mn_nz = fminf(mn_nz, __shfl_down(mn_nz, off));
-        mx_nz = fmaxf(mx_nz, __shfl_down(mx_nz, off));
-        negl += __shfl_down(negl, off);
-        zerl += __shfl_down(zerl, off);
-        cntl += __shfl_down(cntl, off);
-    }
-    __shared__ MinMaxPartial sh[4];
-    __shared__ unsigned long long shc[4];
-    if ((threadIdx.x & 63) == 0) {
-        MinMaxPartial q; q.mn = mn; q.mx = mx; q.cnt = 0; q.neg = negl; q.zer = zerl; q.mn_nz = mn_nz; q.mx_nz = mx_nz;
-        sh[threadIdx.x >> 6] = q; shc[threadIdx.x >> 6] = cntl;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        MinMaxPartial p = sh[0];
-        unsigned long long tot = shc[0];
-        for (int w = 1; w < 4; w++) {
-            p.mn = fminf(p.mn, sh[w].mn); p.mx = fmaxf(p.mx, sh[w].mx); p.neg += sh[w].neg; p.zer += sh[w].zer;
-            p.mn_nz = fminf(p.mn_nz, sh[w].mn_nz); p.mx_nz = fmaxf(p.mx_nz, sh[w].mx_nz);
-            tot += shc[w];
-        }
-        part[blockIdx.x] = p;
-        if (nzeroed && tot) atomicAdd(nzeroed, tot);
-    }
-}
-
-extern "C" size_t nnc_prune_stats_workspace_bytes(int64_t n) { return ((nnc_prune_workspace_bytes(n) + 255) & ~(size_t)255) + nnc_minmax_workspace_bytes(n); }
-
-extern "C" int nnc_prune_stats_f32(float *x, int64_t n, float q, int std_smooth, uint8_t *mask, float *stats_dev, int64_t *nzeroed_dev,
-                                   float *minmax4_dev, int64_t *signs_dev, void *ws, size_t ws_bytes, void *stream)
-{
-    if (n <= 0 || !x || !mask || !stats_dev || !minmax4_dev || !signs_dev || !ws) return fail(NNC_EINVAL, "nnc_prune_stats_f32: bad argument (n must be > 0)");
-    if (ws_bytes < nnc_prune_stats_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_prune_stats_f32: workspace too small");
-    if (std_smooth) {
-        float *wsf = reinterpret_cast<float *>(ws);
-        float *scal = wsf;          // [0] mean, [1] q
-        float *chunks = wsf + 16;
-        const int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
-        int rc;
-        hipLaunchKernelGGL(k_set_f32, dim3(1), dim3(1), 0, S(stream), q, scal + 1);
-        LAUNCHCHK("k_set_f32");
-        if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, chunks, stream))) return rc;
-        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_MEAN, nullptr, scal, stream))) return rc;
-        if ((rc = nnc_chunk_sums_f32(x, n, 1, scal, chunks, stream))) return rc;
-        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_STD, scal + 1, stats_dev, stream))) return rc; // stats = {sigma, sigma * q}
-    } else {
-        hipLaunchKernelGGL(k_set_thr, dim3(1), dim3(1), 0, S(stream), q, stats_dev);
-        LAUNCHCHK("k_set_thr");
-    }
-    if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
-    MinMaxPartial *part = reinterpret_cast<MinMaxPartial *>(reinterpret_cast<unsigned char *>(ws) + ((nnc_prune_workspace_bytes(n) + 255) & ~(size_t)255));
-    const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
-    const int grid = std::min(stream_grid((n + 3) / 4, 256, 4), cu_count() * 8);
-    if (vec) NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold_stats<true>), dim3(grid), dim3(256), 0, S(stream), x, n, stats_dev + 1, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev), part);
-    else NNC_LAUNCH_PROF(NNC_PROF_THRESHOLD, (k_threshold_stats<false>), dim3(grid), dim3(256), 0, S(stream), x, n, stats_dev + 1, mask, reinterpret_cast<unsigned long long *>(nzeroed_dev), part);
-    LAUNCHCHK("k_threshold_stats");
-    hipLaunchKernelGGL(k_minmax_final, dim3(1), dim3(256), 0, S(stream), part, grid, minmax4_dev, (long long *)nullptr, reinterpret_cast<long long *>(signs_dev));
-    LAUNCHCHK("k_minmax_final");
-    return NNC_OK;
-}
-
-// Everything LayerStats wants of one (whole, single-GPU) vector, enqueued by one call: NumPy-exact mean and variance
-// (the two chunk-sum passes and their folds) and the min / max / sign pass.
-extern "C" size_t nnc_layer_stats_workspace_bytes(int64_t n)
-{
-    const size_t nch = (size_t)((n + NNC_CHUNK - 1) / NNC_CHUNK);
-    return ((2 * nch * sizeof(float) + 255) & ~(size_t)255) + nnc_minmax_workspace_bytes(n);
-}
-
-extern "C" int nnc_layer_stats_f32(const float *x, int64_t n, float *out6_dev, int64_t *signs_dev, void *ws, size_t ws_bytes,
-                                   void *stream)
-{
-    if (n <= 0 || !x || !out6_dev || !signs_dev || !ws) return fail(NNC_EINVAL, "nnc_layer_stats_f32: bad argument (n must be > 0)");
-    if (ws_bytes < nnc_layer_stats_workspace_bytes(n)) return fail(NNC_ENOSPACE, "nnc_layer_stats_f32: workspace too small");
-    const int64_t nch = (n + NNC_CHUNK - 1) / NNC_CHUNK;
-    float *c1 = reinterpret_cast<float *>(ws), *c2 = c1 + nch;
-    unsigned char *mm_ws = reinterpret_cast<unsigned char *>(ws) + ((2 * (size_t)nch * sizeof(float) + 255) & ~(size_t)255);
-    int rc;
-    if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, c1, stream))) return rc;
-    if ((rc = nnc_fold_f32(c1, nch, n, NNC_FOLD_MEAN, nullptr, out6_dev, stream))) return rc;           // [0] = mean
-    if ((rc = nnc_chunk_sums_f32(x, n, 1, out6_dev, c2, stream))) return rc;
-    if ((rc = nnc_fold_f32(c2, nch, n, NNC_FOLD_MEAN, nullptr, out6_dev + 1, stream))) return rc;       // [1] = variance
-    return minmax_impl(x, n, 0, out6_dev + 2, nullptr, signs_dev, mm_ws, nnc_minmax_workspace_bytes(n), stream); // [2..5]
-}
-
-// bin(x) = #{ steps[i] <= x } - 1 for non-decreasing steps (np.linspace is monotone), which is
-// exactly "steps[b] <= x < steps[b+1]"; x >= steps[31] (the maximum itself) falls in no bin.
-template <bool VEC>
-__global__ __launch_bounds__(256) void k_hist31(const float *__restrict__ x, int64_t n, int skip_zeros,
-                                                const float *__restrict__ steps,
-                                                unsigned long long *__restrict__ counts)
-{
-    __shared__ unsigned h[32][32]; // [bin][replica]; replica = lane & 31 -> bank = replica
-    __shared__ float st[32];
-    for (int i = threadIdx.x; i < 32 * 32; i += 256) (&h[0][0])[i] = 0;
-    if (threadIdx.x < 32) st[threadIdx.x] = steps[threadIdx.x];
-    __syncthreads();
-    float s[32];
-#pragma unroll
-    for (int i = 0; i < 32; i++) s[i] = st[i];
-    const int rep = threadIdx.x & 31;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-#define H1(v) do { float v_ = (v); if (!(skip_zeros && v_ == 0.0f)) { int c_ = 0; _Pragma("unroll") for (int i = 0; i < 32; i++) c_ += (v_ >= s[i]); if (c_ >= 1 && c_ <= 31) atomicAdd(&h[c_ - 1][rep], 1u); } } while (0)
-    int64_t done = 0;
-    if (VEC) {
-        const int64_t nvec = n >> 2;
-        const float4 *x4 = reinterpret_cast<const float4 *>(x);
-        for (int64_t v = tid; v < nvec; v += nthreads) {
-            float4 a = x4[v];
-            H1(a.x); H1(a.y); H1(a.z); H1(a.w);
-        }
-        done = nvec << 2;
-    }
-    for (int64_t i = done + tid; i < n; i += nthreads) H1(x[i]);
-#undef H1
-    __syncthreads();
-    if (threadIdx.x < 31) {
-        unsigned long long t = 0;
-        for (int r = 0; r < 32; r++) t += h[threadIdx.x][r];
-        if (t) atomicAdd(&counts[threadIdx.x], t);
-    }
-}
-
-extern "C" int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps32_dev,
-                              int64_t *counts_dev, void *stream)
-{
-    if (n < 0 || !steps32_dev || !counts_dev || (n > 0 && !x)) return fail(NNC_EINVAL, "nnc_hist31_f32: bad argument");
-    if (n == 0) return NNC_OK;
-    int grid = stream_grid((n + 3) / 4, 256, 2);
-    const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    if (vec) hipLaunchKernelGGL((k_hist31<true>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, steps32_dev, reinterpret_cast<unsigned long long *>(counts_dev));
-    else hipLaunchKernelGGL((k_hist31<false>), dim3(grid), dim3(256), 0, S(stream), x, n, skip_zeros, steps32_dev, reinterpret_cast<unsigned long long *>(counts_dev));
-    LAUNCHCHK("k_hist31");
-    return NNC_OK;
-}
-
-// ranks_out[i] = #{ j : xs[j] < values[i] } in an ascending vector (lower bound; the same float32 comparison the histogram
-// kernel makes): the 31 bin counts of get_weight_distribution (utility.py:366-372) are differences of 32 such ranks.
-__global__ __launch_bounds__(64) void k_rank_sorted(const float *__restrict__ xs, long long n, const float *__restrict__ values, int m,
-                                                    long long *__restrict__ ranks_out)
-{
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= m) return;
-    const float v = values[i];
-    long long lo = 0, hi = n;
-    while (lo < hi) { const long long mid = (lo + hi) >> 1; if (xs[mid] < v) lo = mid + 1; else hi = mid; }
-    ranks_out[i] = lo;
-}
-
-extern "C" int nnc_rank_sorted_f32(const float *x_sorted, int64_t n, const float *values_dev, int32_t m, int64_t *ranks_out_dev, void *stream)
-{
-    if (n < 0 || m < 0 || (m > 0 && (!values_dev || !ranks_out_dev)) || (n > 0 && !x_sorted)) return fail(NNC_EINVAL, "nnc_rank_sorted_f32: bad argument");
-    if (m == 0) return NNC_OK;
-    hipLaunchKernelGGL(k_rank_sorted, dim3((m + 63) / 64), dim3(64), 0, S(stream), x_sorted, (long long)n, values_dev, (int)m, reinterpret_cast<long long *>(ranks_out_dev));
-    LAUNCHCHK("k_rank_sorted");
-    return NNC_OK;
-}
-
-template <typename LT>
-__global__ __launch_bounds__(256) void k_bincount(const LT *__restrict__ labels, int64_t n, int k,
-                                                  unsigned long long *__restrict__ counts)
-{
-    extern __shared__ unsigned hb[]; // [k][8] replicas
-    for (int i = threadIdx.x; i < k * 8; i += 256) hb[i] = 0;
-    __syncthreads();
-    const int rep = threadIdx.x & 7;
-    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = tid; i < n; i += nthreads) {
-        int l = labels[i];
-        if (l < k) atomicAdd(&hb[l * 8 + rep], 1u);
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < k; j += 256) {
-        unsigned long long t = 0;
-        for (int r = 0; r < 8; r++) t += hb[j * 8 + r];
-        if (t) atomicAdd(&counts[j], t);
-    }
-}
-
-extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int32_t k, int64_t *counts_dev, void *stream)
-{
-    if (n < 0 || k <= 0 || k > NNC_KMAX || !counts_dev || (n > 0 && !labels)) return fail(NNC_EINVAL, "nnc_bincount: bad argument");
-    if (label_bytes != 1 && label_bytes != 2) return fail(NNC_EINVAL, "nnc_bincount: label_bytes must be 1 or 2");
-    if (n == 0) return NNC_OK;
-    int grid = stream_grid(n, 256 * 8, 2);
-    size_t lds = (size_t)k * 8 * sizeof(unsigned);
-    if (label_bytes == 1) hipLaunchKernelGGL((k_bincount<uint8_t>), dim3(grid), dim3(256), lds, S(stream), reinterpret_cast<const uint8_t *>(labels), n, k, reinterpret_cast<unsigned long long *>(counts_dev));
-    else hipLaunchKernelGGL((k_bincount<uint16_t>), dim3(grid), dim3(256), lds, S(stream), reinterpret_cast<const uint16_t *>(labels), n, k, reinterpret_cast<unsigned long long *>(counts_dev));
-    LAUNCHCHK("k_bincount");
-    return NNC_OK;
-}
+#include "nnc_common.hpp"
+#include "nnc_km_shared.hpp"
 
 // ======================================================================================
 // 4. Lloyd k-means
@@ -892,75 +34,7 @@ extern "C" int nnc_bincount(const void *labels, int label_bytes, int64_t n, int3
 // address when R = 32).  Workgroups flush to NSHARD global shards with 64-bit atomics;
 // integer addition makes the result independent of any ordering.
 //
-#define KM_THREADS 1024
-#define KL_RKEYS 16384 // candidate keys an empty-cluster event inside the one-workgroup loop may have (16 per thread)
-#define KM_NSHARD 8
-#define KM_GMAX 32768
-#define KM_CNT_SAT 31
-#define KM_P_BITS 11 // cell entry: first candidate (sorted position, < 2048) | min(count-1, 31) << 11
-#define KM_P_MASK 2047u
-#define KM_OVF_MAX 1024     // cells with a saturated count keep their exact candidate range in a side list
-#define KM_OVF_ALL 2047u    // ... or, if even that list is full, scan every centre
-// Few centres and a small grid: k_finalize builds the cell table itself (its one busy wave plus fifteen helper waves
-// that sleep until the zones are known), which saves the k_cells launch where a launch is a third of the iteration.
-#define KM_FUSE_GLOG2 11
-#define KM_FUSE_KMAX 64
-#ifndef KM_RING
-#define KM_RING 4 // float4 loads kept in flight per thread
-#endif
-
-struct KmTab {
-    float2 cand[NNC_KMAX];   // sorted: (c~, fl(c~*c~))
-    uint16_t orig[NNC_KMAX]; // sorted position -> original centroid index (lowest index among equal centres)
-    uint16_t perm[NNC_KMAX]; // the full sorted permutation of all k centres (duplicates included)
-    uint32_t ovf[KM_OVF_MAX]; // crowded cells (more than 31 candidates): first | last << 16, indexed by the cell entry
-    int32_t n_ovf;
-    int32_t ku;              // number of DISTINCT centre values = entries of cand/orig; equal centres never win (ties go to the lowest index)
-    int32_t pad_[2];
-    uint16_t cell[KM_GMAX];  // p_lo | (min(cnt-1, 31) << 11)
-    double zl[NNC_KMAX], zr[NNC_KMAX]; // zone of every distinct centre: outside [zl, zr] (centred x) it cannot be the float32 arg-min
-    int32_t gc[NNC_KMAX], hc[NNC_KMAX]; // the same in cells (monotone): centre p can open cells <= gc[p], close cells >= hc[p]; k_cells turns them into cell[]
-};
-
-struct KmWs {
-    nnc_kmeans_status st;
-    nnc_kmeans_params p;
-    int32_t cur;       // which KmTab / centre set is current
-    int32_t glog2, rlog2;
-    int32_t reloc_fail; // the windowed farthest-sample selection could not prove its result: redo it the long way
-    int32_t spec_go;    // the relocation chain enqueued behind an iteration "in case" has an event to settle (k_reloc_windows decides)
-    float inv;         // cells per unit: cell = (int)((x~ - lo) * inv)
-    int32_t cells_pending; // k_finalize left new zones: k_cells has to rebuild tab[cur].cell
-    int32_t ku_cur;    // = tab[cur].ku, here so that k_cells learns it in its first round of loads
-    float pad1;
-    float c[2][NNC_KMAX];        // centred centres in ORIGINAL index order; [cur] current, [cur^1] previous
-    long long partials[2 * NNC_KMAX]; // sums then counts, original index order (all-reduced across ranks)
-    long long partials_local[2 * NNC_KMAX]; // this rank's own sums/counts of the last accumulated iteration
-    long long prev_counts[NNC_KMAX];        // label counts of the previous iteration (before any relocation edit)
-    long long shard_sum[KM_NSHARD][NNC_KMAX]; // sorted index order of tab[cur]
-    unsigned long long shard_cnt[KM_NSHARD][NNC_KMAX];
-    // k_bounds: long stretches of samples whose cluster float32 cannot tell from the zones alone, cut into tiles any wave
-    // may take (two self-validating words per record, see k_bounds); emptied by the kernel that consumes the sums
-    // what k_bounds needs of the CURRENT table, at an address that does not depend on which of the two tables is current
-    // (one round of loads less at the head of every iteration); k_finalize writes it next to tab[cur]
-    struct Bnd { int32_t ku, pad; double zr[NNC_KMAX], zl[NNC_KMAX]; float2 cand[NNC_KMAX]; uint16_t orig[NNC_KMAX]; } bnd;
-    int32_t q_n, q_searched; // records published; waves of an announced pass (help_hint) that are through their searches -- whatever they had to publish is out
-    int32_t help_hint, help_pad; // the previous pass published long stretches: this one had better look at the queue (k_finalize sets it)
-    long long hint_a[NNC_KMAX], hint_b[NNC_KMAX]; // where k_bounds found boundary j last time: the next search starts there
-    unsigned long long q_w0[NNC_KMAX], q_w1[NNC_KMAX];
-    int32_t q_next[NNC_KMAX];
-    // k_lloyd (the one-workgroup loop, nnc_lloyd.hpp): `wide` = the next iteration needs the multi-workgroup pass (centres closer
-    // than float32 can tell apart, a search that did not settle): the k_bounds / k_finalize pair enqueued behind the loop "in case"
-    // runs only then and clears it; kl_budget = iterations the launches of the current host call may still run
-    int32_t wide, kl_budget;
-    unsigned long long kl_trace[24]; // diagnostics build: time per phase of k_lloyd (10 ns ticks), summed over the fit
-    int32_t kl_stats[8]; // [0] iterations the loop ran, [1] its launches, [2] of them with centres changing places, [3] iterations handed over, [4] iterations the wide pair ran, [5] empty-cluster events the loop settled itself
-    unsigned long long kl_keys[KL_RKEYS]; // candidate keys of such an event (kl_relocate)
-    int32_t bnd_phi[NNC_KMAX]; // per boundary j of the last k_bounds pass: the highest centre that could still win below U_j (the finalize step labels the undecided samples of an empty-cluster event with it, km_finalize_relocate)
-    unsigned long long kl_mkeys[40960]; // candidate keys of a MASS empty-cluster event settled by the finalize step (kl_relocate_mass, KL_MKEYS)
-    float kl_hL[2 * NNC_KMAX], kl_hR[2 * NNC_KMAX]; // per search (two a boundary: its ranks hint_a / hint_b): the threshold the rank was found for, the local density there (samples per unit)
-    KmTab tab[2];
-};
+// (constants, KmTab, KmWs: nnc_km_shared.hpp)
 
 extern "C" size_t nnc_kmeans_workspace_bytes(int32_t k)
 {
@@ -1394,163 +468,6 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
 }
 
 
-// NumPy's pairwise float32 sum of n <= 8192 values by a whole workgroup (>= 256 threads).  The
-// split tree (n/2 rounded down to a multiple of 8, leaves of <= 128) is laid out as a binary
-// heap in LDS (node i -> children 2i, 2i+1; depth <= 7), leaves are summed by 8 lanes each, and
-// the tree is folded level by level.  F(i) returns element i.  All threads get the result.
-
-template <bool WAVE_ONLY, typename F>
-__device__ float block_pairwise_sum(F elem, int n, PwHeap *hp)
-{
-    const int tid = threadIdx.x, nthr = blockDim.x;
-    if (n <= LEAF) { // a single leaf: eight lanes of the first wave, no tree
-        if (tid < 8) {
-            float res = 0.0f;
-            if (n < 8) {
-                for (int i = 0; i < n; i++) res += elem(i);
-            } else {
-                float r = elem(tid);
-                const int lim = n - (n % 8);
-                for (int i = 8; i < lim; i += 8) r += elem(i + tid);
-                r = r + __shfl_xor(r, 1);
-                r = r + __shfl_xor(r, 2);
-                r = r + __shfl_xor(r, 4);
-                res = r;
-                for (int i = lim; i < n; i++) res += elem(i);
-            }
-            if (tid == 0) hp->val[1] = res;
-        }
-        if (WAVE_ONLY) wave_lds_fence(); // (the caller is a single wave and n <= LEAF: no workgroup barrier anywhere)
-        else __syncthreads();
-        return hp->val[1];
-    }
-    for (int i = tid; i < 256; i += nthr) { hp->start[i] = 0; hp->len[i] = 0; hp->val[i] = 0.0f; }
-    __syncthreads();
-    if (tid == 0) { hp->start[1] = 0; hp->len[1] = n; }
-    __syncthreads();
-    int depth = 0; // levels with anything to split: a node of length l > 128 has children of about l/2
-    while (depth < 7 && ((n + (1 << depth) - 1) >> depth) > LEAF) depth++;
-    if (depth < 7) depth++; // rounding to multiples of 8 can push one child just over the leaf size
-    for (int lev = 0; lev < depth; lev++) {
-        const int i = (1 << lev) + tid;
-        if (tid < (1 << lev)) {
-            const int l = hp->len[i];
-            if (l > LEAF) {
-                int n2 = l / 2; n2 -= n2 % 8;
-                hp->start[2 * i] = hp->start[i]; hp->len[2 * i] = n2;
-                hp->start[2 * i + 1] = hp->start[i] + n2; hp->len[2 * i + 1] = l - n2;
-            }
-        }
-        __syncthreads();
-    }
-    // leaves: 8 lanes per leaf (a group of 8 lanes stays together in the loop)
-    const int j = tid & 7;
-    for (int node = 1 + (tid >> 3); node < (2 << depth) && node < 256; node += (nthr >> 3)) {
-        const int l = hp->len[node];
-        if (l > 0 && l <= LEAF) {
-            const int st = hp->start[node];
-            float res;
-            if (l < 8) {
-                res = 0.0f;
-                for (int i = 0; i < l; i++) res += elem(st + i);
-            } else {
-                float r = elem(st + j);
-                const int lim = l - (l % 8);
-                for (int i = 8; i < lim; i += 8) r += elem(st + i + j);
-                r = r + __shfl_xor(r, 1);
-                r = r + __shfl_xor(r, 2);
-                r = r + __shfl_xor(r, 4);
-                res = r;
-                for (int i = lim; i < l; i++) res += elem(st + i);
-            }
-            if (j == 0) hp->val[node] = res;
-        }
-    }
-    __syncthreads();
-    for (int lev = depth - 1; lev >= 0; lev--) {
-        const int i = (1 << lev) + tid;
-        if (tid < (1 << lev) && hp->len[i] > LEAF) hp->val[i] = hp->val[2 * i] + hp->val[2 * i + 1];
-        __syncthreads();
-    }
-    return hp->val[1];
-}
-
-// The same tree by ONE wave on its own (n <= 2048: at most 32 leaves), wave-level LDS fences instead of workgroup barriers:
-// for the K-sized sums of the finalize step, where sixteen waves meeting at eight barriers cost more than the arithmetic.
-// Every lane of the calling wave returns the sum; the other waves of the workgroup must not touch *hp meanwhile.
-template <typename F>
-__device__ float wave_pairwise_sum(F elem, int n, PwHeap *hp)
-{
-    const int lane = threadIdx.x & 63;
-    if (n <= LEAF) {
-        if (lane < 8) {
-            float res = 0.0f;
-            if (n < 8) {
-                for (int i = 0; i < n; i++) res += elem(i);
-            } else {
-                float r = elem(lane);
-                const int lim = n - (n % 8);
-                for (int i = 8; i < lim; i += 8) r += elem(i + lane);
-                r = r + __shfl_xor(r, 1);
-                r = r + __shfl_xor(r, 2);
-                r = r + __shfl_xor(r, 4);
-                res = r;
-                for (int i = lim; i < n; i++) res += elem(i);
-            }
-            if (lane == 0) hp->val[1] = res;
-        }
-        wave_lds_fence();
-        return hp->val[1];
-    }
-    hp->start[lane] = 0; hp->len[lane] = 0; hp->val[lane] = 0.0f;
-    wave_lds_fence();
-    if (lane == 0) { hp->start[1] = 0; hp->len[1] = n; }
-    wave_lds_fence();
-    int depth = 0;
-    while (depth < 5 && ((n + (1 << depth) - 1) >> depth) > LEAF) depth++;
-    if (depth < 5) depth++; // rounding to multiples of 8 can push one child just over the leaf size
-    for (int lev = 0; lev < depth; lev++) {
-        const int i = (1 << lev) + lane;
-        if (lane < (1 << lev)) {
-            const int l = hp->len[i];
-            if (l > LEAF) {
-                int n2 = l / 2; n2 -= n2 % 8;
-                hp->start[2 * i] = hp->start[i]; hp->len[2 * i] = n2;
-                hp->start[2 * i + 1] = hp->start[i] + n2; hp->len[2 * i + 1] = l - n2;
-            }
-        }
-        wave_lds_fence();
-    }
-    const int j8 = lane & 7;
-    for (int node = 1 + (lane >> 3); node < (2 << depth) && node < 64; node += 8) {
-        const int l = hp->len[node];
-        if (l > 0 && l <= LEAF) {
-            const int st = hp->start[node];
-            float res;
-            if (l < 8) {
-                res = 0.0f;
-                for (int i = 0; i < l; i++) res += elem(st + i);
-            } else {
-                float r = elem(st + j8);
-                const int lim = l - (l % 8);
-                for (int i = 8; i < lim; i += 8) r += elem(st + i + j8);
-                r = r + __shfl_xor(r, 1);
-                r = r + __shfl_xor(r, 2);
-                r = r + __shfl_xor(r, 4);
-                res = r;
-                for (int i = lim; i < l; i++) res += elem(st + i);
-            }
-            if (j8 == 0) hp->val[node] = res;
-        }
-    }
-    wave_lds_fence();
-    for (int lev = depth - 1; lev >= 0; lev--) {
-        const int i = (1 << lev) + lane;
-        if (lane < (1 << lev) && hp->len[i] > LEAF) hp->val[i] = hp->val[2 * i] + hp->val[2 * i + 1];
-        wave_lds_fence();
-    }
-    return hp->val[1];
-}
 
 
 // ---- the rank-boundary iteration (value-sorted vector + block prefix sums) ---------------------
@@ -1583,14 +500,6 @@ __device__ float wave_pairwise_sum(F elem, int n, PwHeap *hp)
 __host__ __device__ __forceinline__ int km_tile_len(int ncand) { int t = (2 * KM_TILE / (ncand < 2 ? 2 : ncand)) & ~63; return t < 64 ? 64 : t; }
 #define KM_Q_VALID (1ull << 62)
 
-// a value every lane holds alike, moved to scalar registers (so that the control flow that depends on it is scalar)
-__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ long long uni_ll(long long v)
-{
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xFFFFFFFFll));
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
 
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
@@ -2237,10 +1146,7 @@ __global__ __launch_bounds__(KM_THREADS) void k_prefix_top(long long *__restrict
 }
 
 // ---- finalize / prepare kernel (one workgroup) -------------------------------------------
-#define FIN_INIT 0          // build the table for the initial centres
-#define FIN_FROM_SHARDS 1   // single GPU: reduce shards -> partials -> finalize
-#define FIN_FROM_PARTIALS 2 // multi GPU / resume: partials already hold the global sums
-#define FIN_PACK_ONLY 3     // reduce shards -> partials, nothing else
+// (FIN_* modes of the finalize step: nnc_km_shared.hpp)
 
 // 1 / d, a little too large rather than too small (float32 reciprocal widened by 2^-20): a zone end that comes out a hair
 // further from its midpoint is still a valid zone, and the division is the slowest thing in the zone loop
@@ -3132,8 +2038,8 @@ static int km_ensure_cells(KmWs *w, const nnc_kmeans_params *p, int which, void 
 
 // reloc_xs: the value-sorted vector, for callers that want the finalize step of a rank-boundary iteration to settle small
 // empty-cluster events itself (km_finalize_relocate: nnc_kmeans_fit); nullptr: every event pauses (what nnc_kmeans_iterate shows)
-static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume, void *stream, void *host_mapped = nullptr,
-                              uint64_t ticket = 0, bool cond = false, const float *reloc_xs = nullptr)
+int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume, void *stream, void *host_mapped,
+                       uint64_t ticket, bool cond, const float *reloc_xs)
 {
     // p == nullptr: the caller does not know the fit's parameters (nnc_kmeans_finalize): full width, k_cells builds the table
     const int k = p ? p->k : 0;
@@ -3162,7 +2068,7 @@ static int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int
     return NNC_OK;
 }
 
-static int km_check(void *ws, const nnc_kmeans_params *p, const char *who)
+int km_check(void *ws, const nnc_kmeans_params *p, const char *who)
 {
     if (!ws || !p) return fail(NNC_EINVAL, std::string(who) + ": null workspace/params");
     if (p->k < 1 || p->k > NNC_KMAX - 8) return fail(NNC_EINVAL, std::string(who) + ": k out of range");
@@ -3336,7 +2242,7 @@ extern "C" int nnc_kmeans_prefix_build(const float *x_sorted, const nnc_kmeans_p
 
 // one pass of per-cluster sums / counts over this rank's vector: by rank boundaries if the caller attached block prefix sums of a
 // sorted vector (p->prefix_dev), else the streaming kernel
-static int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream, int which = 0)
+int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, void *stream, int which)
 {
     if (p->prefix_dev && p->n > 0) {
         if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return fail(NNC_EINVAL, "rank-boundary iteration: the sorted vector must be 16-byte aligned");
@@ -3419,7 +2325,7 @@ static int km_launch_lloyd_round(const float *xs, KmWs *w, const nnc_kmeans_para
 #define KM_LLOYD_ROUNDS 6      // rounds nnc_kmeans_fit enqueues per look-in
 
 static std::atomic<int> g_lds_attr_set[NNC_MAX_DEVICES]; // function attributes are per device
-static int km_set_lds_attr()
+int km_set_lds_attr()
 {
     const int dev = current_device();
     if (g_lds_attr_set[dev].load(std::memory_order_acquire)) return NNC_OK;
@@ -3712,359 +2618,6 @@ extern "C" int nnc_kmeans_assign(const float *x, void *ws, const nnc_kmeans_para
 }
 
 
-
-// ======================================================================================
-// 4c. A whole fit of a SHORT tensor on chip, in the reference's own arithmetic
-//
-// For n <= NNC_REF_NMAX weights and k <= NNC_REF_KMAX centres one workgroup runs everything KMeans.fit does
-// (utility.py:237-238 -> sklearn _kmeans.py:1427-1554, 624-752) without leaving the chip: NumPy's float32 mean and variance
-// (the same pairwise tree as nnc_chunk_sums_f32), the centring, then per iteration the brute-force E-step with scikit-learn's
-// float32 expression, the M-step as scikit-learn runs it on one thread -- float32 running sums IN SAMPLE ORDER
-// (_k_means_lloyd.pyx:215-218) --, empty-cluster relocation, averaging with float32(1 / count), centre shift, the two
-// stopping rules, the final E-step.  With the sums in the reference's order the result is the reference's, bit for bit
-// (centres, indices, n_iter_), where the exact-integer sums of the long-vector path stay within its summation error; what
-// remains open is what scikit-learn itself leaves to numpy.argpartition (pairing and ties at a relocation cut: reported).
-// A sequential sum cannot be spread over lanes, so a wave takes a cluster and walks the label vector 64 samples at a time
-// (ballot of the members, one add per member from the lanes' registers): the cost of an iteration is the size of the largest
-// cluster times a few nanoseconds, which is why this is the path of short tensors only.
-// ======================================================================================
-#define REF_NMAX NNC_REF_NMAX
-#define REF_KMAX NNC_REF_KMAX
-#define REF_PER (REF_NMAX / KM_THREADS)
-
-struct RefOut { int32_t n_iter, stop, n_relocations, reloc_ties, reloc_multi, pad; float x_mean, tol; };
-
-// NumPy's pairwise sum of n <= 128 float32 (one leaf: eight strided accumulators, combined as a tree, then the ragged tail),
-// by one wave on its own; every lane returns the sum.
-template <typename F> __device__ __forceinline__ float wave_leaf_sum(F elem, int n)
-{
-    const int l8 = threadIdx.x & 7;
-    float res = 0.0f;
-    if (n < 8) {
-        for (int i = 0; i < n; i++) res += elem(i);
-    } else {
-        float r = elem(l8);
-        const int lim = n - (n % 8);
-        for (int i = 8; i < lim; i += 8) r += elem(i + l8);
-        r = r + __shfl_xor(r, 1);
-        r = r + __shfl_xor(r, 2);
-        r = r + __shfl_xor(r, 4);
-        res = r;
-        for (int i = lim; i < n; i++) res += elem(i);
-    }
-    return res;
-}
-
-// One link of sixteen running sums: on entry lane 15 of every row of 16 lanes holds that row's sum so far (s) and lane r the
-// row's next value (v; +0.0 beyond the end of the row's list, which leaves a sum as it is: a float32 sum that started at
-// +0.0 is never -0.0).  The sum moves to lane 0 (row rotate), lane 0 adds its value, then fifteen adds each take the sum from
-// the lane below (row shift: lane 0 has no lane below and is left alone), so that lane r ends with s + v0 + ... + vr added in
-// exactly that order.  One VALU instruction per member and row; the s_nop are the two wait states a DPP read of a register
-// written by the instruction before needs, which the compiler does not insert inside an asm block.
-#define REF_DPP_ADD "s_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-__device__ __forceinline__ float ref_chain16(float s, float v)
-{
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\tv_add_f32 %0, %0, %1\n\t" REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD
-                     REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD REF_DPP_ADD "s_nop 1\n\t"
-                 : "+v"(s)
-                 : "v"(v));
-    return s;
-}
-
-__global__ __launch_bounds__(KM_THREADS) void k_fit_reference(const float *__restrict__ x, int n, const float *__restrict__ init, int k, int max_iter,
-                                                             float tol_rel, uint8_t *__restrict__ labels_out, float *__restrict__ values_out,
-                                                             float *__restrict__ centers_out, long long *__restrict__ counts_out, RefOut *__restrict__ out)
-{
-    __shared__ float xc[REF_NMAX];
-    __shared__ float dist[REF_NMAX]; // the members of every cluster in sample order, cluster after cluster (M-step); the squared distances (relocation)
-    __shared__ uint8_t labs[2][REF_NMAX];
-    __shared__ __align__(16) float cen[REF_KMAX], csq[REF_KMAX];
-    __shared__ float cnew[REF_KMAX], sums[REF_KMAX], wic[REF_KMAX], sq[REF_KMAX];
-    __shared__ unsigned hist[REF_KMAX];
-    __shared__ int base[REF_KMAX];
-    // tab[label][chunk of 64 samples]: members of the cluster in the chunk, then where the chunk's first member goes;
-    // the start-up statistics use the same bytes for their tree
-    __shared__ __align__(16) unsigned char scratch[REF_KMAX * (REF_NMAX / 64) * 2];
-    static_assert(sizeof(PwHeap) <= sizeof(scratch), "scratch holds the pairwise-sum tree");
-    PwHeap &heap = *reinterpret_cast<PwHeap *>(scratch);
-    uint16_t(*tab)[REF_NMAX / 64] = reinterpret_cast<uint16_t(*)[REF_NMAX / 64]>(scratch);
-    __shared__ unsigned long long wave_key[KM_THREADS / 64];
-    __shared__ int wave_idx[KM_THREADS / 64];
-    __shared__ int s_flag, s_empty[REF_KMAX], s_nempty, s_far[REF_KMAX], s_moved;
-    __shared__ float s_tot;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int k4 = (k + 3) & ~3;
-    const int nbits = k > 1 ? 32 - __builtin_clz((unsigned)(k - 1)) : 0; // bits of a centroid index
-#ifdef NNC_DIAG
-    long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = wall_clock64(); // phase times of thread 0, 10 ns units, behind the result block
-#define REFSTAMP(p) { const long long now_ = wall_clock64(); tph[p] += now_ - tlast; tlast = now_; }
-#else
-#define REFSTAMP(p)
-#endif
-
-    // ---- X_mean = X.mean(axis=0); tol = np.mean(np.var(X, axis=0)) * tol; X -= X_mean   (all float32, NumPy's pairwise sums)
-    for (int i = tid; i < n; i += KM_THREADS) xc[i] = x[i];
-    __syncthreads();
-    const float s1 = block_pairwise_sum<false>([&](int i) { return xc[i]; }, n, &heap);
-    const float mean = (float)((double)s1 / (double)n);
-    __syncthreads();
-    const float s2 = block_pairwise_sum<false>([&](int i) { const float a = xc[i] - mean; return a * a; }, n, &heap);
-    const float var = (float)((double)s2 / (double)n);
-    const float tol = var * tol_rel;
-    __syncthreads();
-    float xv[REF_PER];
-#pragma unroll
-    for (int u = 0; u < REF_PER; u++) {
-        const int i = tid + u * KM_THREADS;
-        xv[u] = i < n ? xc[i] - mean : 0.0f;
-        if (i < n) { xc[i] = xv[u]; labs[1][i] = 255; }
-    }
-    // centres beyond k: never the arg-min (c^2 = +inf)
-    if (tid < REF_KMAX) { const float c = tid < k ? init[tid] - mean : 0.0f; cen[tid] = c; csq[tid] = tid < k ? c * c : __builtin_inff(); hist[tid] = 0u; }
-    for (int q = tid; q < k * (REF_NMAX / 64) / 2; q += KM_THREADS) reinterpret_cast<unsigned *>(scratch)[q] = 0u;
-    if (tid == 0) s_nempty = 0;
-    __syncthreads();
-
-    // E-step: first strict minimum of fl(c^2) + fl(-2 * fl(x * c)) over the centres in index order; index histogram, and per
-    // sample its rank among the members of its cluster inside its chunk
-    int rank[REF_PER], lfin[REF_PER];
-    auto estep = [&](uint8_t *__restrict__ lab, const uint8_t *__restrict__ lab_prev) -> int {
-        float best[REF_PER];
-        int l[REF_PER];
-#pragma unroll
-        for (int u = 0; u < REF_PER; u++) { best[u] = __builtin_inff(); l[u] = 0; }
-        for (int j = 0; j < k4; j += 4) {
-            const float4 c4 = *reinterpret_cast<const float4 *>(&cen[j]), q4 = *reinterpret_cast<const float4 *>(&csq[j]);
-            const float cc[4] = {c4.x, c4.y, c4.z, c4.w}, qq[4] = {q4.x, q4.y, q4.z, q4.w};
-#pragma unroll
-            for (int t = 0; t < 4; t++) {
-#pragma unroll
-                for (int u = 0; u < REF_PER; u++) {
-                    const float d = qq[t] + (-2.0f * (xv[u] * cc[t]));
-                    if (d < best[u] || (j + t) == 0) { best[u] = d; l[u] = j + t; }
-                }
-            }
-        }
-        int same = 1;
-#pragma unroll
-        for (int u = 0; u < REF_PER; u++) {
-            const int i = tid + u * KM_THREADS; // the wave's lanes hold 64 consecutive samples: chunk wv + 16 u
-            const bool valid = i < n;
-            // the lanes of the chunk with the same index (a ballot per index bit); rank[u] = how many of them come before
-            unsigned long long peers = __ballot(valid);
-            for (int b = 0; b < nbits; b++) {
-                const bool bit = (l[u] >> b) & 1;
-                const unsigned long long mb = __ballot(valid && bit);
-                peers &= bit ? mb : ~mb;
-            }
-            rank[u] = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(peers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)peers, 0u));
-            lfin[u] = l[u];
-            if (valid) {
-                lab[i] = (uint8_t)l[u];
-                if (lab_prev) same &= (lab_prev[i] == (uint8_t)l[u]);
-                if (rank[u] == 0) {
-                    const int c = __popcll(peers);
-                    tab[l[u]][wv + u * (KM_THREADS / 64)] = (uint16_t)c;
-                    atomicAdd(&hist[l[u]], (unsigned)c);
-                }
-            }
-        }
-        return same;
-    };
-
-    REFSTAMP(0)
-    int n_iter = 0, stop = 2, n_reloc = 0, n_ties = 0, n_multi = 0;
-    bool strict = false;
-    int cur = 0;
-    for (int it = 0; it < max_iter; it++) {
-        uint8_t *lab = labs[cur];
-        const int all_same = __syncthreads_and(estep(lab, labs[cur ^ 1]));
-        REFSTAMP(1)
-        // ---- M-step: float32 running sums in sample order (_k_means_lloyd.pyx:215-218).  The members of every cluster are first
-        // put, in sample order, into a stretch of `dist` of their own (a stable counting sort: stretch start = members of
-        // lower clusters, from the histogram; inside it, members in earlier chunks, from a wave scan of the table row; then the
-        // rank inside the chunk).  Then a row of 16 lanes per cluster, four clusters per wave, walks its stretch 16 members
-        // per link (ref_chain16): one add per member, in sample order.
-        if (wv == KM_THREADS / 64 - 1) { // (this wave also lists the empty clusters)
-            const bool e0 = lane < k && hist[lane] == 0u, e1 = lane + 64 < k && hist[lane + 64] == 0u;
-            const unsigned long long m0 = __ballot(e0), m1 = __ballot(e1);
-            if (e0) s_empty[__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = lane;
-            if (e1) s_empty[__popcll(m0) + __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = lane + 64;
-            if (lane == 0) s_nempty = __popcll(m0) + __popcll(m1);
-        }
-        for (int j = wv; j < k; j += KM_THREADS / 64) {
-            const int cj = (int)hist[j];
-            int below = 0;
-            for (int q = lane; q < j; q += 64) below += (int)hist[q];
-            for (int off = 32; off >= 1; off >>= 1) below += __shfl_xor(below, off);
-            if (lane == 0) base[j] = below;
-            if (cj == 0) continue;
-            const int mine = (int)tab[j][lane];
-            int incl = mine;
-            for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-            tab[j][lane] = (uint16_t)(below + incl - mine);
-        }
-        __syncthreads();
-        REFSTAMP(2)
-#pragma unroll
-        for (int u = 0; u < REF_PER; u++) {
-            const int i = tid + u * KM_THREADS;
-            if (i < n) dist[(int)tab[lfin[u]][wv + u * (KM_THREADS / 64)] + rank[u]] = xv[u];
-        }
-        __syncthreads();
-        for (int r0 = 0; r0 < k; r0 += KM_THREADS / 16) {
-            const int j = r0 + wv * 4 + (lane >> 4), rl = lane & 15;
-            const int cj = j < k ? (int)hist[j] : 0, bj = j < k ? base[j] : 0;
-            int maxc = max(cj, __shfl_xor(cj, 16));
-            maxc = uni_i(max(maxc, __shfl_xor(maxc, 32)));
-            float s = 0.0f;
-            float v = rl < cj ? dist[bj + rl] : 0.0f;
-            for (int c0 = 0; c0 < maxc; c0 += 16) {
-                const float vn = c0 + 16 + rl < cj ? dist[bj + c0 + 16 + rl] : 0.0f;
-                s = ref_chain16(s, v);
-                v = vn;
-            }
-            if (rl == 15 && j < k) { sums[j] = s; wic[j] = (float)cj; }
-        }
-        // (waves without a cluster get here at once) the table is cleared for the next iteration
-        for (int q = tid; q < k * (REF_NMAX / 64) / 2; q += KM_THREADS) reinterpret_cast<unsigned *>(scratch)[q] = 0u;
-        __syncthreads();
-        REFSTAMP(3)
-        // ---- _relocate_empty_clusters_dense (_k_means_common.pyx:167-211)
-        const int n_empty = s_nempty;
-        if (n_empty > 0) {
-            for (int i = tid; i < n; i += KM_THREADS) { const float t = xc[i] - cen[lab[i]]; dist[i] = t * t; }
-            if (tid == 0) s_flag = 0;
-            __syncthreads();
-            // the n_empty farthest samples: descending distance, equal distances by descending value, then by descending index
-            // (numpy leaves the order to its introselect; this is the order it was observed to leave on 69 of 70 reference fits)
-            for (int r = 0; r <= n_empty && r < n; r++) { // one more than needed: the runner-up shows a tie at the cut
-                unsigned long long bk = 0ull;
-                int bi = -1;
-                for (int i = tid; i < n; i += KM_THREADS) {
-                    const float d = dist[i];
-                    if (d >= 0.0f) {
-                        const unsigned xb = __float_as_uint(xc[i]);
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)((xb & 0x80000000u) ? ~xb : (xb | 0x80000000u));
-                        if (bi < 0 || key > bk || (key == bk && i > bi)) { bk = key; bi = i; }
-                    }
-                }
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const unsigned long long ok = __shfl_xor(bk, off);
-                    const int oi = __shfl_xor(bi, off);
-                    if (oi >= 0 && (bi < 0 || ok > bk || (ok == bk && oi > bi))) { bk = ok; bi = oi; }
-                }
-                if (lane == 0) { wave_key[wv] = bk; wave_idx[wv] = bi; }
-                __syncthreads();
-                if (tid == 0) {
-                    unsigned long long k0 = 0ull;
-                    int i0 = -1;
-                    for (int w = 0; w < KM_THREADS / 64; w++)
-                        if (wave_idx[w] >= 0 && (i0 < 0 || wave_key[w] > k0 || (wave_key[w] == k0 && wave_idx[w] > i0))) { k0 = wave_key[w]; i0 = wave_idx[w]; }
-                    if (r < n_empty) { s_far[r] = i0; dist[i0] = -1.0f; } // taken (n_empty < k <= n: there is always one left)
-                    else if (i0 >= 0) {
-                        // the runner-up: a DIFFERENT sample value at the same non-zero distance as the last one taken is a tie
-                        // at the cut (which of the two scikit-learn takes is numpy.argpartition's business)
-                        const int last = s_far[n_empty - 1];
-                        const float tl = xc[last] - cen[lab[last]], dl = tl * tl;
-                        s_flag = (dl != 0.0f) && ((unsigned)(k0 >> 32) == __float_as_uint(dl)) && (xc[i0] != xc[last]);
-                    }
-                }
-                __syncthreads();
-            }
-            if (tid == 0) {
-                const int first = s_far[0];
-                const float t0 = xc[first] - cen[lab[first]], dmax = t0 * t0;
-                if (dmax != 0.0f) { // (np.max(distances) == 0: nothing is relocated)
-                    for (int q = 0; q < n_empty; q++) {
-                        const int nw = s_empty[q], fi = s_far[q], old = lab[fi];
-                        const float v = xc[fi] * 1.0f;
-                        sums[old] = sums[old] - v;
-                        sums[nw] = v;
-                        wic[nw] = 1.0f;
-                        wic[old] = wic[old] - 1.0f;
-                    }
-                    s_moved = 1;
-                } else s_moved = 0;
-            }
-            __syncthreads();
-            if (s_moved) { n_reloc++; if (n_empty > 1) n_multi++; if (s_flag) n_ties++; }
-        }
-        REFSTAMP(4)
-        // ---- _average_centers (_k_means_common.pyx:274-296): in place and in index order, so an empty cluster copies the biggest
-        // one averaged if that comes before it and its raw sum otherwise; _center_shift; NumPy's sum of the squared shifts.
-        // One wave, two clusters per lane.
-        if (wv == 0) {
-            unsigned key = 0u; // the first maximum of the counts: largest (count bits, 255 - index)
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int j = lane + 64 * h;
-                if (j < k) key = max(key, (__float_as_uint(wic[j]) & 0xFFFFFF00u) | (unsigned)(255 - j)); // (counts <= 4096: the low 8 mantissa bits are 0)
-            }
-            for (int off = 32; off >= 1; off >>= 1) key = max(key, (unsigned)__shfl_xor((int)key, off));
-            const int amax = 255 - (int)(key & 0xFFu);
-            const float big_raw = sums[amax], big_avg = big_raw * (float)(1.0 / (double)wic[amax]);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int j = lane + 64 * h;
-                if (j < k) {
-                    const float w = wic[j];
-                    const float c = w > 0.0f ? sums[j] * (float)(1.0 / (double)w) : (amax < j ? big_avg : big_raw);
-                    const float t = c - cen[j], sh = sqrtf(t * t);
-                    cnew[j] = c;
-                    sq[j] = sh * sh;
-                }
-            }
-            wave_lds_fence();
-            const float tot = wave_leaf_sum([&](int i) { return sq[i]; }, k);
-            if (lane == 0) s_tot = tot;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int j = lane + 64 * h;
-                if (j < k) { const float c = cnew[j]; cen[j] = c; csq[j] = c * c; }
-                hist[j] = 0u;
-            }
-        }
-        __syncthreads();
-        REFSTAMP(5)
-        n_iter = it + 1;
-        if (all_same) { strict = true; stop = 3; break; }
-        if (s_tot <= tol) { stop = 1; break; }
-        cur ^= 1;
-    }
-    // ---- labels of the final centres unless the label test stopped the loop (then cur still names that iteration's labels and
-    // the histogram is rebuilt from them); centres += X_mean; cluster_centers_[labels_]
-    uint8_t *lab = labs[cur];
-    if (!strict) estep(lab, nullptr);
-    else
-        for (int i = tid; i < n; i += KM_THREADS) atomicAdd(&hist[lab[i]], 1u);
-    if (tid < k) { cnew[tid] = cen[tid] + mean; centers_out[tid] = cnew[tid]; }
-    __syncthreads();
-    for (int i = tid; i < n; i += KM_THREADS) {
-        labels_out[i] = lab[i];
-        if (values_out) values_out[i] = cnew[lab[i]];
-    }
-    if (counts_out && tid < k) counts_out[tid] = (long long)hist[tid];
-#ifdef NNC_DIAG
-    REFSTAMP(6)
-    if (tid == 0)
-        for (int q = 0; q < 8; q++) reinterpret_cast<long long *>(out + 1)[q] = tph[q];
-#endif
-    if (tid == 0) { out->n_iter = n_iter; out->stop = stop; out->n_relocations = n_reloc; out->reloc_ties = n_ties; out->reloc_multi = n_multi; out->pad = 0; out->x_mean = mean; out->tol = tol; }
-}
-
-extern "C" int nnc_kmeans_fit_reference_f32(const float *x, int32_t n, const float *centers_init_dev, int32_t k, int32_t max_iter, float tol,
-                                            uint8_t *labels_out, float *values_out, float *centers_out, int64_t *counts_out,
-                                            void *result_dev, void *stream)
-{
-    if (!x || n < 1 || n > REF_NMAX || !centers_init_dev || k < 1 || k > REF_KMAX || n < k || max_iter < 1 || !labels_out || !centers_out || !result_dev)
-        return fail(NNC_EINVAL, "nnc_kmeans_fit_reference_f32: bad argument (1 <= k <= NNC_REF_KMAX, k <= n <= NNC_REF_NMAX)");
-    hipLaunchKernelGGL(k_fit_reference, dim3(1), dim3(KM_THREADS), 0, S(stream), x, (int)n, centers_init_dev, (int)k, (int)max_iter, tol, labels_out,
-                       values_out, centers_out, reinterpret_cast<long long *>(counts_out), reinterpret_cast<RefOut *>(result_dev));
-    LAUNCHCHK("k_fit_reference");
-    return NNC_OK;
-}
 
 // ======================================================================================
 // 4b. farthest-sample selection for the empty-cluster relocation
@@ -4846,7 +3399,6 @@ extern "C" int nnc_kmeans_relocate_checked(void *ws, const float *cand_x_dev, co
 
 // The whole windowed relocation as one call: windows -> candidates -> exact distances -> selection
 // + proof + relocation -> resumed finalize.  No host read; the outcome shows in the next status.
-static size_t reloc_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
 extern "C" int32_t nnc_kmeans_reloc_window(int64_t n, int32_t n_empty)
 {
@@ -4937,12 +3489,11 @@ static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans
 // (status.paused == 2: the proof of a windowed selection failed; paused == 1: windows not applicable, the strict-convergence
 // check is due, or the scratch is too small).  The caller handles that and calls again.
 // --------------------------------------------------------------------------------------
-static int km_wait_ticket(volatile unsigned long long *word, unsigned long long ticket, hipStream_t stream);
 int nnc_wait_ticket_(void *host_ticket, uint64_t ticket, void *stream) // (shared with nnc_layer.hip)
 {
     return km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(host_ticket), (unsigned long long)ticket, S(stream));
 }
-static int km_wait_ticket(volatile unsigned long long *word, unsigned long long ticket, hipStream_t stream)
+int km_wait_ticket(volatile unsigned long long *word, unsigned long long ticket, hipStream_t stream)
 {
     unsigned long long spins = 0;
     bool synced = false;
@@ -5217,322 +3768,3 @@ extern "C" int nnc_kmeans_set_done_if(void *ws, const int32_t *flag_dev, int32_t
     return NNC_OK;
 }
 
-// ======================================================================================
-// 5. Huffman code lengths (host)
-// ======================================================================================
-extern "C" int nnc_huffman_lengths(const int64_t *counts, int32_t k, uint8_t *lengths_out, int64_t *hist_out,
-                                   int64_t *total_bits_out)
-{
-    if (!counts || k <= 0 || !lengths_out) return fail(NNC_EINVAL, "nnc_huffman_lengths: bad argument");
-    struct Node { int64_t w; int32_t minsym; int32_t left, right; };
-    std::vector<Node> nodes;
-    nodes.reserve(2 * (size_t)k);
-    auto cmp = [&](int a, int b) {
-        if (nodes[a].w != nodes[b].w) return nodes[a].w > nodes[b].w;
-        return nodes[a].minsym > nodes[b].minsym;
-    };
-    std::priority_queue<int, std::vector<int>, decltype(cmp)> pq(cmp);
-    for (int s = 0; s < k; s++) {
-        lengths_out[s] = 0;
-        if (counts[s] < 0) return fail(NNC_EINVAL, "nnc_huffman_lengths: negative count");
-        if (counts[s] > 0) { nodes.push_back({counts[s], s, -1, -1}); pq.push((int)nodes.size() - 1); }
-    }
-    if (pq.size() == 1) lengths_out[nodes[pq.top()].minsym] = 1;
-    else if (pq.size() > 1) {
-        while (pq.size() > 1) {
-            int a = pq.top(); pq.pop();
-            int b = pq.top(); pq.pop();
-            nodes.push_back({nodes[a].w + nodes[b].w, std::min(nodes[a].minsym, nodes[b].minsym), a, b});
-            pq.push((int)nodes.size() - 1);
-        }
-        // depth of every leaf
-        std::vector<std::pair<int, int>> stack;
-        stack.push_back({pq.top(), 0});
-        while (!stack.empty()) {
-            auto [n, d] = stack.back();
-            stack.pop_back();
-            if (nodes[n].left < 0) { lengths_out[nodes[n].minsym] = (uint8_t)std::min(d, 255); continue; }
-            stack.push_back({nodes[n].left, d + 1});
-            stack.push_back({nodes[n].right, d + 1});
-        }
-    }
-    if (hist_out) for (int i = 0; i < 65; i++) hist_out[i] = 0;
-    int64_t total = 0;
-    for (int s = 0; s < k; s++) {
-        if (hist_out) hist_out[std::min<int>(lengths_out[s], 64)]++;
-        total += (int64_t)lengths_out[s] * counts[s];
-    }
-    if (total_bits_out) *total_bits_out = total;
-    return NNC_OK;
-}
-
-// ======================================================================================
-// 6. Multi-GPU exchange inside the library: RCCL over xGMI
-//
-// One process per GPU.  The only data-path exchange of a sharded fit is the all-reduce (SUM) of the
-// 2K int64 per-cluster sums / counts between the streaming pass and the finalize step of every Lloyd
-// iteration (about 4 KB at K = 256: latency bound), plus, per empty-cluster event, the verdict word and
-// the ranks' farthest-sample keys.  All of it is enqueued here on the caller's stream, back to back with
-// the kernels: no host round trip per iteration, no second stream, no event.
-//
-// RCCL is bound at run time (dlopen): a process that never shards a vector never loads it, and one that
-// runs beside PyTorch shares the librccl PyTorch has already mapped instead of a second copy.
-// ======================================================================================
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-
-struct RcclApi {
-    void *handle = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-};
-static RcclApi g_rccl;
-static std::mutex g_rccl_mu;
-
-static int rccl_load()
-{
-    std::lock_guard<std::mutex> lock(g_rccl_mu);
-    if (g_rccl.handle) return NNC_OK;
-    void *h = nullptr;
-    // the copy that is already mapped (PyTorch's), else the system's
-    for (const char *name : {"librccl.so", "librccl.so.1"}) { if ((h = dlopen(name, RTLD_NOW | RTLD_NOLOAD))) break; }
-    if (!h) for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { if ((h = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break; }
-    if (!h) return fail(NNC_ENODEV, std::string("cannot load librccl: ") + dlerror());
-    RcclApi a;
-    a.handle = h;
-#define RSYM(field, sym) do { a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, sym)); if (!a.field) return fail(NNC_ENODEV, std::string("librccl lacks ") + sym); } while (0)
-    RSYM(GetUniqueId, "ncclGetUniqueId"); RSYM(CommInitRank, "ncclCommInitRank"); RSYM(CommDestroy, "ncclCommDestroy");
-    RSYM(AllReduce, "ncclAllReduce"); RSYM(AllGather, "ncclAllGather"); RSYM(GetErrorString, "ncclGetErrorString");
-#undef RSYM
-    g_rccl = a;
-    return NNC_OK;
-}
-
-#define RCCLCHK(expr)                                                                                  \
-    do {                                                                                               \
-        ncclResult_t r_ = (expr);                                                                      \
-        if (r_ != ncclSuccess) return fail(NNC_EHIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
-    } while (0)
-
-struct NncComm { ncclComm_t comm; int rank, world; };
-
-// NNC_OK if librccl can be bound in this process (nothing is created): every rank asks before any of them enters
-// nnc_comm_init, which blocks until all ranks have entered it.
-extern "C" int nnc_comm_available(void) { return rccl_load(); }
-
-extern "C" int nnc_comm_unique_id(void *id_out, size_t len)
-{
-    if (!id_out || len < NNC_COMM_ID_BYTES) return fail(NNC_EINVAL, "nnc_comm_unique_id: buffer shorter than NNC_COMM_ID_BYTES");
-    static_assert(NNC_COMM_ID_BYTES == sizeof(ncclUniqueId), "NNC_COMM_ID_BYTES");
-    int rc = rccl_load();
-    if (rc) return rc;
-    ncclUniqueId id;
-    RCCLCHK(g_rccl.GetUniqueId(&id));
-    std::memcpy(id_out, &id, sizeof(id));
-    return NNC_OK;
-}
-
-extern "C" int nnc_comm_init(void **comm_out, const void *id, size_t len, int32_t rank, int32_t world)
-{
-    if (!comm_out || !id || len < NNC_COMM_ID_BYTES || world < 1 || rank < 0 || rank >= world) return fail(NNC_EINVAL, "nnc_comm_init: bad argument");
-    int rc = rccl_load();
-    if (rc) return rc;
-    ncclUniqueId uid;
-    std::memcpy(&uid, id, sizeof(uid));
-    NncComm *c = new NncComm{nullptr, rank, world};
-    ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);   // on the calling thread's current device
-    if (r != ncclSuccess) { delete c; return fail(NNC_EHIP, std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); }
-    *comm_out = c;
-    return NNC_OK;
-}
-
-extern "C" int nnc_comm_destroy(void *comm)
-{
-    if (!comm) return NNC_OK;
-    NncComm *c = reinterpret_cast<NncComm *>(comm);
-    if (c->comm) RCCLCHK(g_rccl.CommDestroy(c->comm));
-    delete c;
-    return NNC_OK;
-}
-
-extern "C" int nnc_comm_rank(void *comm) { return comm ? reinterpret_cast<NncComm *>(comm)->rank : -1; }
-extern "C" int nnc_comm_world(void *comm) { return comm ? reinterpret_cast<NncComm *>(comm)->world : -1; }
-
-extern "C" int nnc_comm_allreduce(void *comm, void *buf_dev, int64_t count, int32_t dtype, int32_t op, void *stream)
-{
-    if (!comm || count < 0 || (count > 0 && !buf_dev)) return fail(NNC_EINVAL, "nnc_comm_allreduce: bad argument");
-    if (count == 0) return NNC_OK;
-    ncclDataType_t dt;
-    switch (dtype) { case NNC_I64: dt = ncclInt64; break; case NNC_I32: dt = ncclInt32; break; case NNC_F32: dt = ncclFloat32; break;
-    default: return fail(NNC_EINVAL, "nnc_comm_allreduce: dtype"); }
-    ncclRedOp_t ro;
-    switch (op) { case NNC_SUM: ro = ncclSum; break; case NNC_MAX: ro = ncclMax; break; case NNC_MIN: ro = ncclMin; break;
-    default: return fail(NNC_EINVAL, "nnc_comm_allreduce: op"); }
-    RCCLCHK(g_rccl.AllReduce(buf_dev, buf_dev, (size_t)count, dt, ro, reinterpret_cast<NncComm *>(comm)->comm, S(stream)));
-    return NNC_OK;
-}
-
-extern "C" int nnc_comm_allgather(void *comm, const void *send_dev, void *recv_dev, int64_t bytes_per_rank, void *stream)
-{
-    if (!comm || bytes_per_rank < 0 || (bytes_per_rank > 0 && (!send_dev || !recv_dev))) return fail(NNC_EINVAL, "nnc_comm_allgather: bad argument");
-    if (bytes_per_rank == 0) return NNC_OK;
-    RCCLCHK(g_rccl.AllGather(send_dev, recv_dev, (size_t)bytes_per_rank, ncclInt8, reinterpret_cast<NncComm *>(comm)->comm, S(stream)));
-    return NNC_OK;
-}
-
-// `iters` Lloyd iterations of a sharded fit, enqueued back to back: streaming pass over this rank's shard -> pack ->
-// all-reduce of the 2K int64 sums / counts -> finalize (identical on every rank); the look-in rides on the last launch.
-extern "C" int nnc_kmeans_iterate_sharded(void *comm, const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters,
-                                          void *host_mapped, uint64_t ticket, void *stream)
-{
-    int rc = km_check(ws, pp, "nnc_kmeans_iterate_sharded");
-    if (rc) return rc;
-    if (!comm) return fail(NNC_EINVAL, "nnc_kmeans_iterate_sharded: null communicator");
-    const nnc_kmeans_params p = *pp;
-    if (p.n > 0 && !x) return fail(NNC_EINVAL, "nnc_kmeans_iterate_sharded: null x");
-    if (iters < 1 || (host_mapped && (reinterpret_cast<uintptr_t>(host_mapped) & 7) != 0))
-        return fail(NNC_EINVAL, "nnc_kmeans_iterate_sharded: iters < 1 or unaligned host pointer");
-    if ((rc = km_set_lds_attr())) return rc;
-    KmWs *w = reinterpret_cast<KmWs *>(ws);
-    NncComm *c = reinterpret_cast<NncComm *>(comm);
-    for (int i = 0; i < iters; i++) {
-        if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-        if ((rc = km_launch_finalize(w, &p, FIN_PACK_ONLY, 0, stream))) return rc;
-        RCCLCHK(g_rccl.AllReduce(w->partials, w->partials, (size_t)(2 * p.k), ncclInt64, ncclSum, c->comm, S(stream)));
-        const bool last = i == iters - 1;
-        if ((rc = km_launch_finalize(w, &p, FIN_FROM_PARTIALS, 0, stream, last ? host_mapped : nullptr, ticket))) return rc;
-    }
-    return NNC_OK;
-}
-
-// The ranks' farthest-sample lists (each descending, `per` keys, padded with 0 or -1) merged into the `m` largest,
-// descending.  A key's place is the number of keys that sort before it: for every list a binary search, ties between
-// lists by list number (equal keys are interchangeable samples).  One workgroup.
-__global__ __launch_bounds__(KM_THREADS) void k_merge_keys(const long long *__restrict__ lists, int nlists, int per, long long *__restrict__ out, int m)
-{
-    const int total = nlists * per;
-    for (int i = threadIdx.x; i < m; i += KM_THREADS) out[i] = 0ll;
-    __syncthreads();
-    for (int t = threadIdx.x; t < total; t += KM_THREADS) {
-        const int li = t / per, pos = t % per;
-        const long long key = lists[t];
-        if (key <= 0) continue; // padding
-        int place = pos; // the keys before it in its own list
-        for (int l = 0; l < nlists; l++) {
-            if (l == li) continue;
-            const long long *a = lists + (size_t)l * per;
-            // number of keys in list l that sort before `key`: strictly greater, or equal and l < li
-            int lo = 0, hi = per;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; const long long v = a[mid]; if (v > key || (v == key && l < li)) lo = mid + 1; else hi = mid; }
-            place += lo;
-        }
-        if (place < m) out[place] = key;
-    }
-}
-
-extern "C" int nnc_merge_keys(const int64_t *lists_dev, int32_t nlists, int32_t per, int64_t *out_dev, int32_t m, void *stream)
-{
-    if (!lists_dev || !out_dev || nlists < 1 || per < 1 || m < 1) return fail(NNC_EINVAL, "nnc_merge_keys: bad argument");
-    hipLaunchKernelGGL(k_merge_keys, dim3(1), dim3(KM_THREADS), 0, S(stream), reinterpret_cast<const long long *>(lists_dev), (int)nlists, (int)per,
-                       reinterpret_cast<long long *>(out_dev), (int)m);
-    LAUNCHCHK("k_merge_keys");
-    return NNC_OK;
-}
-
-extern "C" size_t nnc_kmeans_reloc_scratch_bytes_sharded(int32_t k, int32_t window, int32_t world)
-{
-    if (world < 1) return 0;
-    const size_t base = nnc_kmeans_reloc_scratch_bytes(k, window);
-    return base ? base + reloc_align(8 * (size_t)(NNC_KMAX + 8)) * (size_t)(world + 2) : 0;
-}
-
-// nnc_kmeans_relocate_windowed for a sharded vector, collectives included: every rank selects and proves from the windows of
-// its own shard -> all-reduce (MAX) of the verdict word -> all-gather of the keys -> merge -> the same edits on every rank
-// (or none, if any proof failed) -> resumed finalize.
-extern "C" int nnc_kmeans_relocate_windowed_sharded(void *comm, const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t n_empty,
-                                                    void *scratch_dev, size_t scratch_bytes, void *stream)
-{
-    int rc = km_check(ws, p, "nnc_kmeans_relocate_windowed_sharded");
-    if (rc) return rc;
-    if (!comm) return fail(NNC_EINVAL, "nnc_kmeans_relocate_windowed_sharded: null communicator");
-    NncComm *c = reinterpret_cast<NncComm *>(comm);
-    const int32_t window = nnc_kmeans_reloc_window(p->n, n_empty); // (the caller made sure that every rank's shard allows it)
-    if (window == 0 || n_empty > NNC_KMAX) return fail(NNC_EINVAL, "nnc_kmeans_relocate_windowed_sharded: not applicable");
-    if (!scratch_dev || (reinterpret_cast<uintptr_t>(scratch_dev) & 255) != 0) return fail(NNC_EINVAL, "nnc_kmeans_relocate_windowed_sharded: null or unaligned (256 B) scratch");
-    if (scratch_bytes < nnc_kmeans_reloc_scratch_bytes_sharded(p->k, window, c->world)) return fail(NNC_ENOSPACE, "nnc_kmeans_relocate_windowed_sharded: scratch too small");
-    const size_t base = nnc_kmeans_reloc_scratch_bytes(p->k, window), slot = reloc_align(8 * (size_t)(NNC_KMAX + 8));
-    unsigned char *b = reinterpret_cast<unsigned char *>(scratch_dev) + base;
-    long long *mine = reinterpret_cast<long long *>(b);
-    long long *merged = reinterpret_cast<long long *>(b + slot);
-    long long *all = reinterpret_cast<long long *>(b + 2 * slot);
-    KmWs *w = reinterpret_cast<KmWs *>(ws);
-    const int per = n_empty + 1;
-    if ((rc = nnc_kmeans_reloc_select_local(x_sorted, ws, p, n_empty, scratch_dev, base, reinterpret_cast<int64_t *>(mine), stream))) return rc;
-    RCCLCHK(g_rccl.AllReduce(&w->reloc_fail, &w->reloc_fail, 1, ncclInt32, ncclMax, c->comm, S(stream)));
-    RCCLCHK(g_rccl.AllGather(mine, all, (size_t)per, ncclInt64, c->comm, S(stream)));
-    if ((rc = nnc_merge_keys(reinterpret_cast<const int64_t *>(all), c->world, per, reinterpret_cast<int64_t *>(merged), per, stream))) return rc;
-    if ((rc = nnc_kmeans_relocate_if_proven(ws, reinterpret_cast<const int64_t *>(merged), per, stream))) return rc;
-    return km_launch_finalize(w, p, FIN_FROM_PARTIALS, 1, stream);
-}
-
-// The Lloyd loop of a SHARDED fit as one call (what nnc_kmeans_fit is to the single GPU): batches of iterations with the all-reduce
-// inside (nnc_kmeans_iterate_sharded), the look-ins, batch sizing from the decay of the centre shift, and the windowed relocation of
-// empty clusters with its collectives (nnc_kmeans_relocate_windowed_sharded) -- no host language between two launches.  Every rank
-// makes the same call; the state machine is replicated (the status is the same on every rank after each finalize), so every rank
-// takes the same decisions.  n_min = the shortest shard: whether the windowed relocation applies must come out alike everywhere
-// (the window itself depends on n_empty only).  Comes back when the fit has stopped or needs what only the caller can do
-// (full-pass relocation, strict-convergence check: status.paused != 0).
-// No relocation chain "in case" behind the iterations here: it would put two more collectives behind every one of them.
-extern "C" int nnc_kmeans_fit_sharded(void *comm, const float *x_iter, void *ws, const nnc_kmeans_params *pp, int64_t n_min, int32_t max_batch,
-                                      int32_t sorted, void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped,
-                                      uint64_t *ticket_io, nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream)
-{
-    int rc = km_check(ws, pp, "nnc_kmeans_fit_sharded");
-    if (rc) return rc;
-    if (!comm) return fail(NNC_EINVAL, "nnc_kmeans_fit_sharded: null communicator");
-    if (!host_mapped || !ticket_io || !status_out || (reinterpret_cast<uintptr_t>(host_mapped) & 7) != 0) return fail(NNC_EINVAL, "nnc_kmeans_fit_sharded: null / unaligned pointer");
-    const nnc_kmeans_params p = *pp;
-    if (n_min < 0 || n_min > p.n) return fail(NNC_EINVAL, "nnc_kmeans_fit_sharded: n_min is the shortest shard (0 <= n_min <= n)");
-    if (max_batch < 1) max_batch = 1;
-    const int world = reinterpret_cast<NncComm *>(comm)->world;
-    const size_t slot = sizeof(nnc_kmeans_status) + 8;
-    unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped); // two slots, used alternately
-    int batch = 1; // the first iteration is where duplicate initial centres surface as empty clusters
-    int nwin = 0;
-    double s_prev = -1.0, s_last = -1.0;
-    int i_prev = 0, i_last = 0;
-    for (;;) {
-        const uint64_t ticket = ++(*ticket_io);
-        unsigned char *sl = hb + (ticket & 1) * slot;
-        if ((rc = nnc_kmeans_iterate_sharded(comm, x_iter, ws, &p, batch, sl, ticket, stream))) return rc;
-        if ((rc = km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(sl + sizeof(nnc_kmeans_status)), ticket, S(stream)))) return rc;
-        const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
-        *status_out = st;
-        if (st.done) break;
-        if (st.paused) {
-            const bool strict_check = st.iter >= 1 && st.same_counts;
-            const int32_t window = (sorted && st.paused == 1 && !strict_check) ? nnc_kmeans_reloc_window(n_min, st.n_empty) : 0;
-            if (window == 0 || !reloc_scratch_dev || reloc_scratch_bytes < nnc_kmeans_reloc_scratch_bytes_sharded(p.k, window, world)) break; // the caller's turn
-            if ((rc = nnc_kmeans_relocate_windowed_sharded(comm, x_iter, ws, &p, st.n_empty, reloc_scratch_dev, reloc_scratch_bytes, stream))) return rc;
-            nwin++; // (an unproven selection comes back as paused == 2 with the next look-in, and the caller takes this one back)
-            batch = 1;
-            s_prev = s_last = -1.0;
-            continue;
-        }
-        // size the next batch so that it ends about where the shift crosses the tolerance (as nnc_kmeans_fit does)
-        s_prev = s_last; i_prev = i_last;
-        s_last = (double)st.shift_tot; i_last = st.iter;
-        batch = std::min(max_batch, batch * 2);
-        if (s_prev > 0.0 && s_last > 0.0 && s_prev > s_last && p.tol > 0.0f) {
-            const double rate = std::log(s_prev / s_last) / std::max(1, i_last - i_prev);
-            const double left = s_last > (double)p.tol ? std::log(s_last / (double)p.tol) / rate : 0.0;
-            batch = (int)std::max(1.0, std::min((double)max_batch, std::floor(left * 0.9)));
-        }
-    }
-    if (n_windowed_out) *n_windowed_out = nwin;
-    return NNC_OK;
-}
