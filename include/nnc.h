@@ -257,7 +257,9 @@ size_t nnc_kmeans_workspace_bytes(int32_t k);
  * samples is run by the k_bounds / k_finalize pair enqueued behind every launch of the loop.  Bit-identical trajectory.  The buffer
  * therefore also holds the fine prefixes (one int64 per 64 samples) behind the block / group prefixes.
  * nnc_kmeans_iterate(iters) on this path enqueues min(iters, 32) rounds, each of which runs at least one iteration and all of
- * which together run at most `iters`. */
+ * which together run at most `iters`: a call with iters > 32 may come back with FEWER than `iters` iterations run (every round that
+ * ends in a hand-over to the wide pair, or in an event, uses up one of the 32) -- the contract is "at most iters, at least
+ * min(iters, 32) unless the fit stops or pauses"; read status.iter and call again for the rest. */
 size_t nnc_kmeans_prefix_bytes(int64_t n);
 /* Where the iterations of the fit ran so far (device counters, reset by nnc_kmeans_init): out8[0] iterations run by the
  * one-workgroup loop, [1] launches of it that had work, [2] iterations in which centres changed places, [3] iterations it handed

@@ -2285,9 +2285,11 @@ int km_launch_accumulate(const float *x, KmWs *w, const nnc_kmeans_params *p, vo
 }
 
 // ---- the one-workgroup loop (nnc_lloyd.hpp) and, behind it, the wide pair in case it hands an iteration over --------------------
+#define KL_LDS_LIMIT ((size_t)158 * 1024) // dynamic LDS k_lloyd may ask for (160 KiB a workgroup on gfx950, minus its static part)
 static bool km_lloyd_ok(const nnc_kmeans_params *p, const float *x)
 {
     if (!(p->prefix_dev && p->n > 0 && p->n == p->n_total && (reinterpret_cast<uintptr_t>(x) & 15) == 0)) return false;
+    if (kl_lds_bytes((p->k + 7) & ~7) > KL_LDS_LIMIT) return false; // (the launch-per-iteration pair takes it)
     if (p->flags & NNC_KM_TWO_LAUNCH) return false;
     return (p->flags & NNC_KM_LOOP) || p->k <= NNC_KM_LOOP_KMAX; // (beyond that one compute unit's instruction rate is the bound: include/nnc.h)
 }
@@ -2344,9 +2346,10 @@ int km_set_lds_attr()
     SETATTR((k_assign<1, true, uint16_t>));
     SETATTR((k_assign<1, false, uint16_t>));
 #undef SETATTR
-    // (k_lloyd has a little static LDS of its own -- the workgroup votes -- so it cannot ask for all 160 KiB; K = NNC_KMAX needs 119 KiB)
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd<KM_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    // (k_lloyd has a little static LDS of its own -- the workgroup votes -- so it cannot ask for all 160 KiB: KL_LDS_LIMIT leaves it
+    // 2 KiB; K = NNC_KMAX - 8 needs kl_lds_bytes(1024) = 153 KiB, and km_lloyd_ok refuses a K whose arrays would not fit)
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KL_LDS_LIMIT));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lloyd<KM_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)KL_LDS_LIMIT));
     g_lds_attr_set[dev].store(1, std::memory_order_release);
     return NNC_OK;
 }

@@ -531,7 +531,8 @@ class DeviceKMeans:
         return self.wait(self._ticket)
 
     def iterate(self, iters: int):
-        """Enqueue `iters` Lloyd iterations (no host sync)."""
+        """Enqueue `iters` Lloyd iterations (no host sync).  On the resident-loop path (up to NNC_KM_LOOP_KMAX centres) a call asks for
+        at most 32 rounds, so more than 32 iterations may need a second call: look at status().iter (include/nnc.h, nnc_kmeans_iterate)."""
         if self.group is None:
             nat.check(self.L.nnc_kmeans_iterate(self.x_iter.data_ptr(), self.ws.data_ptr(), ctypes.byref(self.p), int(iters), self.stream))
             return
