@@ -172,8 +172,9 @@ int nnc_hist31_f32(const float *x, int64_t n, int skip_zeros, const float *steps
 
 /* One-time ascending reorder of the vector for the iterations (nnc_kmeans_accumulate /
  * nnc_kmeans_iterate accept any order: integer sums are order independent; on a sorted copy a
- * lane sees runs of equal cluster index and adds them up in registers).  Library radix sort
- * (rocPRIM); not part of the per-iteration path.  nnc_kmeans_assign must get the original. */
+ * lane sees runs of equal cluster index and adds them up in registers).  Hand-written radix sort
+ * (csrc/nnc_sort.hip: four passes of 8 bits over the ordered images of the floats, decoupled look-back; no library sort);
+ * not part of the per-iteration path.  nnc_kmeans_assign must get the original.  n < 2^31. */
 size_t nnc_sort_workspace_bytes(int64_t n);
 int nnc_sort_f32(const float *x, int64_t n, float *sorted_out, void *ws, size_t ws_bytes, void *stream);
 /* The same for a pruned vector with n_neg negative and n_zero zero elements (host counts, e.g.

@@ -918,10 +918,10 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
             const int r = km_claim(&ws->q_n, lane);
             if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
                 published = true;
-                if (lane == 0) {
-                    __hip_atomic_store(&ws->q_w0[r], KM_Q_VALID | ((unsigned long long)j << 40) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&ws->q_w1[r], KM_Q_VALID | ((unsigned long long)phi << 40) | (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                // (EVERY lane stores the record -- the same two words: the publisher sees its own tiles through by reading the queue
+                // like any helper, lane r & 63 reads record r, and only a thread's own store is certain to be in front of its own load)
+                __hip_atomic_store(&ws->q_w0[r], KM_Q_VALID | ((unsigned long long)j << 40) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ws->q_w1[r], KM_Q_VALID | ((unsigned long long)phi << 40) | (unsigned long long)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // (an announced pass: the others wait at the queue until every wave has said whether it had something to publish.
