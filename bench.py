@@ -24,7 +24,17 @@ The JSON line also carries
   roofline_streaming_accumulate : the streaming form of the Lloyd pass (4 B read per weight per launch), which the
                  iterations on a sorted vector no longer need, timed on its own after the timed region;
   cpu_baseline : the same pipeline through NumPy / scikit-learn on the host cores (rank 0, N = 1
-                 only) on a bounded sample of the same vector.
+                 only) on a bounded sample of the same vector;
+  parity       : the GPU fit of the timed region next to that CPU fit (n_iter, centres, index histogram, differing indices, the
+                 k-means objective of both) and next to the committed full-size golden made by the reference itself
+                 (tests/golden/ref_goldens_25m.json, read as data: device == oracle mode B bit for bit; the reference's n_iter).
+
+    python bench.py --config 4 [--gpus N] ...
+
+BASELINE.json configs[4] instead: the 122 tensors of a GPT-2-small-sized model (124.4 M weights), per tensor prune -> 4-bit
+linear-init k-means (K = 16) -> labels + values -> index histogram -> Huffman lengths; the tensors are dealt out to the GPUs
+(pipeline.compress_layers(group=...): replicas, no data-path collective; --shard-above shards the longest ones instead).  The total
+work is fixed ("scaling": "strong").  The driver's default invocation (no --config) stays configs[3], the headline.
 """
 from __future__ import annotations
 
