@@ -1069,21 +1069,36 @@ __global__ __launch_bounds__(256) void k_prefix_blocks(const float *__restrict__
     const long long nblk = (n + KM_PB - 1) / KM_PB;
     long long *__restrict__ pfine = pblk + km_pfine_off(n); // (here: the raw sums of the 64-sample quarters; k_prefix_fine turns them into prefixes)
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
-    for (long long b = wave; b < nblk; b += nwaves) {
-        const long long i0 = b * KM_PB + 4 * lane;
-        long long acc = 0;
-        if ((b + 1) * KM_PB <= n) {
-            const float4 v = *reinterpret_cast<const float4 *>(xs + i0);
-            acc = ((long long)fix_f32(v.x - mean, Sft) + fix_f32(v.y - mean, Sft)) + ((long long)fix_f32(v.z - mean, Sft) + fix_f32(v.w - mean, Sft));
-        } else {
-            for (int u = 0; u < 4; u++) if (i0 + u < n) acc += fix_f32(xs[i0 + u] - mean, Sft);
+    // four blocks a turn, their loads in flight together (one a turn left every wave a chain of a dozen dependent round trips: 21-25 us
+    // for 100 MB)
+    for (long long b0 = wave; b0 < nblk; b0 += 4 * nwaves) {
+        float4 v[4];
+        bool full[4], have[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const long long b = b0 + u * nwaves;
+            have[u] = b < nblk;
+            full[u] = have[u] && (b + 1) * KM_PB <= n;
+            v[u] = full[u] ? *reinterpret_cast<const float4 *>(xs + b * KM_PB + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int off = 1; off <= 8; off <<= 1) acc += __shfl_xor(acc, off); // sixteen lanes = one quarter (64 samples)
-        if ((lane & 15) == 0) pfine[4 * b + (lane >> 4)] = acc;
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        if (lane == 0) pblk[b] = acc;
+        for (int u = 0; u < 4; u++) {
+            if (!have[u]) continue; // (wave-uniform)
+            const long long b = b0 + u * nwaves;
+            const long long i0 = b * KM_PB + 4 * lane;
+            long long acc = 0;
+            if (full[u]) {
+                acc = ((long long)fix_f32(v[u].x - mean, Sft) + fix_f32(v[u].y - mean, Sft)) + ((long long)fix_f32(v[u].z - mean, Sft) + fix_f32(v[u].w - mean, Sft));
+            } else {
+                for (int q = 0; q < 4; q++) if (i0 + q < n) acc += fix_f32(xs[i0 + q] - mean, Sft);
+            }
+#pragma unroll
+            for (int off = 1; off <= 8; off <<= 1) acc += __shfl_xor(acc, off); // sixteen lanes = one quarter (64 samples)
+            if ((lane & 15) == 0) pfine[4 * b + (lane >> 4)] = acc;
+            acc += __shfl_xor(acc, 16);
+            acc += __shfl_xor(acc, 32);
+            if (lane == 0) pblk[b] = acc;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) pblk[nblk] = 0; // one virtual block behind the last: its prefix is the total
 }

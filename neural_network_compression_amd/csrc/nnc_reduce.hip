@@ -41,14 +41,17 @@ __device__ __forceinline__ float xform1(float v, float mean)
 // The ragged last chunk (m < 8192 elements): the generic workgroup-parallel pairwise sum.
 struct PwFrame { int start, len, stage; float left; };
 
-// one wave per full chunk; 4 waves (4 chunks) per workgroup; with a ragged last chunk the grid has one more
-// workgroup, which sums it (so that it runs beside the others instead of in a launch of its own)
+// One WORKGROUP (four waves) per full chunk: wave w takes the 1024-element steps 2w and 2w + 1 (both loaded at once), the eight step
+// nodes meet in LDS and one lane merges them as NumPy's tree does.  (Round 4: one wave used to walk all eight steps of its chunk with
+// one step of loads ahead -- 3052 chunks gave every wave a chain of eight dependent round trips and left two thirds of the wave
+// slots empty: 20.9-23.5 us for 100 MB.)  With a ragged last chunk the grid has one more workgroup, which sums it beside the others.
 template <bool SQDEV, bool VEC>
 __global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x, int64_t nfull,
                                                     const float *__restrict__ mean_dev,
                                                     float *__restrict__ out, int tail)
 {
     __shared__ __align__(16) float lds[4][8 * LEAF_PAD];
+    __shared__ float nodes[8];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *my = lds[wave];
     const float mean = SQDEV ? *mean_dev : 0.0f;
@@ -60,35 +63,27 @@ __global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x,
         if (threadIdx.x == 0) out[nfull] = r;
         return;
     }
-    for (int64_t chunk = (int64_t)blockIdx.x * 4 + wave; chunk < nfull; chunk += gmain * 4) {
-        const float *base = x + chunk * NNC_CHUNK;
-        float node[8];
-        float4 cur[4], nxt[4];
+    for (int64_t chunk = (int64_t)blockIdx.x; chunk < nfull; chunk += gmain) {
+        const float *base = x + chunk * NNC_CHUNK + (int64_t)wave * 2 * STEP_ELEMS;
+        float4 cur[2][4];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (VEC) cur[r] = reinterpret_cast<const float4 *>(base)[lane + 64 * r];
-            else {
-                const float *p = base + 4 * (lane + 64 * r);
-                cur[r] = make_float4(p[0], p[1], p[2], p[3]);
+        for (int st = 0; st < 2; st++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (VEC) cur[st][r] = reinterpret_cast<const float4 *>(base + st * STEP_ELEMS)[lane + 64 * r];
+                else {
+                    const float *p = base + st * STEP_ELEMS + 4 * (lane + 64 * r);
+                    cur[st][r] = make_float4(p[0], p[1], p[2], p[3]);
+                }
             }
         }
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            if (it < 7) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (VEC) nxt[r] = reinterpret_cast<const float4 *>(base + (it + 1) * STEP_ELEMS)[lane + 64 * r];
-                    else {
-                        const float *p = base + (it + 1) * STEP_ELEMS + 4 * (lane + 64 * r);
-                        nxt[r] = make_float4(p[0], p[1], p[2], p[3]);
-                    }
-                }
-            }
+        for (int st = 0; st < 2; st++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 int e = 4 * (lane + 64 * r); // element index inside the 1024-element step
                 int b = e >> 7, pos = e & 127;
-                *reinterpret_cast<float4 *>(&my[b * LEAF_PAD + pos]) = xform4<SQDEV>(cur[r], mean);
+                *reinterpret_cast<float4 *>(&my[b * LEAF_PAD + pos]) = xform4<SQDEV>(cur[st][r], mean);
             }
             wave_lds_fence();
             const float *lp = &my[(lane >> 3) * LEAF_PAD + (lane & 7)];
@@ -102,12 +97,11 @@ __global__ __launch_bounds__(256) void k_chunk_sums(const float *__restrict__ x,
             acc = acc + __shfl_xor(acc, 8);
             acc = acc + __shfl_xor(acc, 16);
             acc = acc + __shfl_xor(acc, 32);
-            node[it] = acc;
-#pragma unroll
-            for (int r = 0; r < 4; r++) cur[r] = nxt[r];
+            if (lane == 0) nodes[2 * wave + st] = acc;
         }
-        float s = ((node[0] + node[1]) + (node[2] + node[3])) + ((node[4] + node[5]) + (node[6] + node[7]));
-        if (lane == 0) out[chunk] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) out[chunk] = ((nodes[0] + nodes[1]) + (nodes[2] + nodes[3])) + ((nodes[4] + nodes[5]) + (nodes[6] + nodes[7]));
+        __syncthreads(); // (nodes[] is reused by the next chunk)
     }
 }
 
@@ -121,8 +115,8 @@ extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const fl
     const int tail = (int)(n % NNC_CHUNK);
     const bool vec = (reinterpret_cast<uintptr_t>(x) & 15) == 0;
     {
-        int64_t blocks = (nfull + 3) / 4;
-        int64_t cap = (int64_t)cu_count() * 8;
+        int64_t blocks = nfull;                  // a workgroup a chunk
+        int64_t cap = (int64_t)cu_count() * 16;  // (LDS: 17 KiB a workgroup)
         int grid = (int)std::min<int64_t>(blocks, cap) + (tail > 0 ? 1 : 0);
         if (sqdev) {
             if (vec) NNC_LAUNCH_PROF(NNC_PROF_CHUNK_SUMS, (k_chunk_sums<true, true>), dim3(grid), dim3(256), 0, S(stream), x, nfull, mean_dev, chunk_out, tail);
