@@ -501,23 +501,57 @@ __host__ __device__ __forceinline__ int km_tile_len(int ncand) { int t = (2 * KM
 #define KM_Q_VALID (1ull << 62)
 
 
+// Wave-wide reductions whose result every lane needs, without the LDS crossbar: __shfl_xor is ds_bpermute_b32 here -- a trip through
+// the LDS pipe and a wait per step, six dependent steps (twelve instructions for 64 bits) a reduction, and a k_bounds wave has four
+// groups of them one behind the other on its critical path (zone ends, the candidate range, the two prefix sums, the sums of a short
+// undecided stretch: 254 ds_bpermute in the kernel, 1.5-2 us of its 10).  Four DPP steps (two quad permutes, the half-row mirror, the
+// row mirror: VALU operand modifiers, no memory pipe) leave every lane of a row of sixteen with the row's result; the four rows are
+// read into scalar registers (v_readlane takes the lane by number, whatever EXEC is) and folded there.  Integer sums and max / min
+// do not depend on the order, so the bits are those of the butterfly.  The whole wave must be active at the call (as for __shfl_xor).
+#define KM_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define KM_DPP_XOR1 0xB1    // quad_perm [1,0,3,2]
+#define KM_DPP_XOR2 0x4E    // quad_perm [2,3,0,1]
+#define KM_DPP_HMIRROR 0x141 // row_half_mirror: lane i of a group of eight <-> 7 - i
+#define KM_DPP_MIRROR 0x140  // row_mirror: lane i of a row of sixteen <-> 15 - i
+template <int CTRL> __device__ __forceinline__ long long km_dpp_ll(long long v)
+{
+    const int lo = KM_DPP((int)v, CTRL), hi = KM_DPP((int)(v >> 32), CTRL);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__device__ __forceinline__ long long km_readlane_ll(long long v, int l)
+{
+    const int lo = __builtin_amdgcn_readlane((int)v, l), hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
 __device__ __forceinline__ long long wave_sum_ll(long long v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += km_dpp_ll<KM_DPP_XOR1>(v); v += km_dpp_ll<KM_DPP_XOR2>(v); v += km_dpp_ll<KM_DPP_HMIRROR>(v); v += km_dpp_ll<KM_DPP_MIRROR>(v);
+    return (km_readlane_ll(v, 0) + km_readlane_ll(v, 16)) + (km_readlane_ll(v, 32) + km_readlane_ll(v, 48));
 }
 __device__ __forceinline__ double wave_max_d(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    v = fmax(v, __longlong_as_double(km_dpp_ll<KM_DPP_XOR1>(__double_as_longlong(v))));
+    v = fmax(v, __longlong_as_double(km_dpp_ll<KM_DPP_XOR2>(__double_as_longlong(v))));
+    v = fmax(v, __longlong_as_double(km_dpp_ll<KM_DPP_HMIRROR>(__double_as_longlong(v))));
+    v = fmax(v, __longlong_as_double(km_dpp_ll<KM_DPP_MIRROR>(__double_as_longlong(v))));
+    const long long b = __double_as_longlong(v);
+    return fmax(fmax(__longlong_as_double(km_readlane_ll(b, 0)), __longlong_as_double(km_readlane_ll(b, 16))),
+                fmax(__longlong_as_double(km_readlane_ll(b, 32)), __longlong_as_double(km_readlane_ll(b, 48))));
 }
 __device__ __forceinline__ double wave_min_d(double v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+    v = fmin(v, __longlong_as_double(km_dpp_ll<KM_DPP_XOR1>(__double_as_longlong(v))));
+    v = fmin(v, __longlong_as_double(km_dpp_ll<KM_DPP_XOR2>(__double_as_longlong(v))));
+    v = fmin(v, __longlong_as_double(km_dpp_ll<KM_DPP_HMIRROR>(__double_as_longlong(v))));
+    v = fmin(v, __longlong_as_double(km_dpp_ll<KM_DPP_MIRROR>(__double_as_longlong(v))));
+    const long long b = __double_as_longlong(v);
+    return fmin(fmin(__longlong_as_double(km_readlane_ll(b, 0)), __longlong_as_double(km_readlane_ll(b, 16))),
+                fmin(__longlong_as_double(km_readlane_ll(b, 32)), __longlong_as_double(km_readlane_ll(b, 48))));
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+    v = max(v, KM_DPP(v, KM_DPP_XOR1)); v = max(v, KM_DPP(v, KM_DPP_XOR2)); v = max(v, KM_DPP(v, KM_DPP_HMIRROR)); v = max(v, KM_DPP(v, KM_DPP_MIRROR));
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // the group prefixes live behind the block prefixes in the caller's buffer
@@ -822,9 +856,7 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
             const int q = lane + 64 * r;
             if (q < ku && q > j && zlv[r] <= Uj) phi = q;
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) phi = max(phi, __shfl_xor(phi, off));
-        phi = uni_i(phi);
+        phi = wave_max_i(phi);
         KBSTAMP(16 * j + 1, 0);
         const bool top = j == ku - 1; // no boundary above the last centre
         // ---- three searches in lock step.  State k: the answer lies in [lo, hi]; hi is n or a position known to satisfy the test
@@ -1336,7 +1368,7 @@ __device__ int km_finalize_relocate(KmWs *__restrict__ ws, const float *__restri
 // (gcell / hcell / ku_out = {ku, cur} filled), i.e. the cell table has to be rebuilt.
 template <int NT, bool ONEWAVE, bool MASS = false>
 __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode, int resume, int *gcell, int *hcell, int *ku_out, const bool lazy = false,
-                                                 const float *__restrict__ reloc_xs = nullptr, const long long reloc_n = 0)
+                                                 const float *__restrict__ reloc_xs = nullptr, const long long reloc_n = 0, const int k_hint = 0)
 {
     static_assert(!ONEWAVE || NT == 64, "the barrier-free form is for a single wave");
     // The threads of this step talk to each other through LDS only; what they write to global memory is for later kernels.  A
@@ -1367,18 +1399,18 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     FSTAMP(0);
     if (tid == 0) ws->cells_pending = 0;
     if (!ONEWAVE && tid < 8) fin_votes[tid] = 0; // (the barrier below is in front of the first vote)
-    {   // the tile queue of the pass that produced these sums (k_bounds) is spent -- for the call that takes the sums of a pass; a
-        // call that resumes behind a relocation (or finds it has nothing to do: the resume of a chain enqueued "in case") leaves
-        // the queue and above all the announcement for the next pass alone (until round 3 the idle resume behind every iteration of
-        // a batch with chains wiped it: the passes that most needed helpers at the queue went without)
-        const bool takes_a_pass = mode != FIN_FROM_PARTIALS; // (sharded: the packing call in front of the all-reduce has taken it)
-        const int qn = takes_a_pass ? min(ws->q_n, (int)NNC_KMAX) : 0;
-        for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
-        if (ONEWAVE) wave_lds_fence(); else __syncthreads(); // every thread has read q_n
-        if (tid == 0 && takes_a_pass) { ws->q_n = 0; ws->q_searched = 0; ws->help_hint = qn > 0; }
-    }
-    // Everything the kernel needs from the workspace header, fetched in one round: on an otherwise idle chip every
-    // DEPENDENT global load costs about a microsecond, and this kernel sits between two streaming passes.
+    // ---- ONE round of loads for everything this step reads.  On an otherwise idle chip every DEPENDENT global load costs about a
+    // microsecond (the lines were written by the kernel in front, on other compute units: each first touch goes to the memory side),
+    // and until round 4 there were four of them one behind the other here -- the queue length, behind a barrier the header, behind
+    // the header's `cur` the order and the previous centres, behind `ku` the shards: 3.6 of the step's 12.5 us.  Nothing below needs
+    // a loaded value for its ADDRESS: both tables' orders and both centre arrays are fetched (the header says which one counts), the
+    // shards of position `tid` whatever the number of distinct centres turns out to be (below the number of centres the LAUNCHER knows,
+    // k_hint, a kernel argument: sixteen waves fetching shards for 1024 positions where 257 are in use took 1.4 us longer than the
+    // four dependent rounds had).  Stores wait until the header has spoken.
+    const int kb = k_hint > 0 ? min(k_hint, (int)NNC_KMAX) : (int)NNC_KMAX;
+    const bool takes_a_pass = mode != FIN_FROM_PARTIALS; // (sharded: the packing call in front of the all-reduce has taken the queue)
+    const bool from_shards = mode == FIN_FROM_SHARDS || mode == FIN_PACK_ONLY;
+    const int qn_raw = takes_a_pass ? ws->q_n : 0;
     const int st_done = ws->st.done, st_paused = ws->st.paused, st_iter = ws->st.iter, reloc_fail = ws->reloc_fail;
     const int spec_go = ws->spec_go;
     const int k = ws->p.k, Sft = ws->p.fix_shift, max_iter = ws->p.max_iter, glog2 = ws->glog2;
@@ -1386,61 +1418,101 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     const long long n_tot = ws->p.n_total;
     const int ku0 = ws->tab[0].ku, ku1 = ws->tab[1].ku;
     int cur = ws->cur;
-    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) return false;
-    if (mode == FIN_FROM_SHARDS && st_paused) return false;
+    // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept its
+    // count (prev_counts); the host runs the full label comparison (strict convergence) only then.
+    const bool track = (mode == FIN_FROM_SHARDS) || (mode == FIN_FROM_PARTIALS && !resume);
+    constexpr int RR = 2; // centres per thread: the launcher picks NT >= k / 2 (64 threads up to 64 centres, 256 up to 256, 1024 beyond)
+    long long pc[RR];
+    float c_both[RR][2];
+    uint16_t pm_both[RR][2], pmn_both[RR][2];
+#pragma unroll
+    for (int r = 0; r < RR; r++) {
+        pc[r] = 0; c_both[r][0] = c_both[r][1] = 0.0f; pm_both[r][0] = pm_both[r][1] = pmn_both[r][0] = pmn_both[r][1] = 0;
+        const int j = tid + r * NT;
+        if (j < kb) {
+            if (track) pc[r] = ws->prev_counts[j];
+            if (mode != FIN_INIT) {
+                c_both[r][0] = ws->c[0][j]; c_both[r][1] = ws->c[1][j];
+                pm_both[r][0] = ws->tab[0].perm[j]; pm_both[r][1] = ws->tab[1].perm[j];
+                if (j + 1 < NNC_KMAX) { pmn_both[r][0] = ws->tab[0].perm[j + 1]; pmn_both[r][1] = ws->tab[1].perm[j + 1]; }
+            }
+        }
+    }
+    long long sh_s[KM_NSHARD];
+    unsigned long long sh_c[KM_NSHARD];
+    uint16_t og_both[2] = {0, 0};
+    const bool sh_pre = from_shards && tid < kb;
+#pragma unroll
+    for (int sh = 0; sh < KM_NSHARD; sh++) { sh_s[sh] = 0; sh_c[sh] = 0; }
+    if (sh_pre) {
+        og_both[0] = ws->tab[0].orig[tid]; og_both[1] = ws->tab[1].orig[tid];
+#pragma unroll
+        for (int sh = 0; sh < KM_NSHARD; sh++) { sh_s[sh] = ws->shard_sum[sh][tid]; sh_c[sh] = ws->shard_cnt[sh][tid]; }
+    }
+    // the tile queue of the pass that produced these sums (k_bounds) is spent -- for the call that takes the sums of a pass; a
+    // call that resumes behind a relocation (or finds it has nothing to do: the resume of a chain enqueued "in case") leaves
+    // the queue and above all the announcement for the next pass alone (until round 3 the idle resume behind every iteration of
+    // a batch with chains wiped it: the passes that most needed helpers at the queue went without).  The counter itself is reset
+    // by thread 0 behind the first barrier of the path taken -- every thread has its copy of it by then (the loop below needs it).
+    const int qn = min(qn_raw, (int)NNC_KMAX);
+    for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
+    FSTAMP(34);
+#define FIN_QUEUE_RESET() do { if (tid == 0 && takes_a_pass) { ws->q_n = 0; ws->q_searched = 0; ws->help_hint = qn > 0; } } while (0)
+#define FIN_LEAVE() do { if (ONEWAVE) wave_lds_fence(); else __syncthreads(); FIN_QUEUE_RESET(); return false; } while (0)
+    if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) FIN_LEAVE();
+    if (mode == FIN_FROM_SHARDS && st_paused) FIN_LEAVE();
     if (mode == FIN_PACK_ONLY && (st_done | st_paused)) {
         // no new iteration was accumulated: hand the all-reduce this rank's own sums again,
         // so that reducing an idle iteration leaves `partials` unchanged
         const int k2 = 2 * k;
         for (int i = tid; i < k2; i += NT) ws->partials[i] = ws->partials_local[i];
-        return false;
+        FIN_LEAVE();
     }
-    if (mode == FIN_FROM_PARTIALS && st_paused && !resume) return false;
+    if (mode == FIN_FROM_PARTIALS && st_paused && !resume) FIN_LEAVE();
     // the resume behind a relocation chain enqueued "in case": only if that chain had an event to settle (k_reloc_windows, the
     // head of every such chain, sets the flag either way; nobody clears it here, where waves still on their way would read it)
-    if (resume == 2 && !spec_go) return false;
+    if (resume == 2 && !spec_go) FIN_LEAVE();
     if (resume && reloc_fail) { // unproven windowed selection: stay paused, tell the host
         if (tid == 0) ws->st.paused = 2;
-        return false;
+        FIN_LEAVE();
     }
 
-    // Could this iteration's labels equal the previous iteration's?  Only if every cluster kept its
-    // count (prev_counts); the host runs the full label comparison (strict convergence) only then.
-    // (loaded up front by original index, so that the loads overlap the shard loads)
-    const bool track = (mode == FIN_FROM_SHARDS) || (mode == FIN_FROM_PARTIALS && !resume);
-    constexpr int RR = 2; // centres per thread: the launcher picks NT >= k / 2 (64 threads up to 64 centres, 256 up to 256, 1024 beyond)
-    long long pc[RR];
-#pragma unroll
-    for (int r = 0; r < RR; r++) { pc[r] = 0; const int j = tid + r * NT; if (track && j < k) pc[r] = ws->prev_counts[j]; }
-    // second (and last) round of loads: the previous centres and the order the E-step of this iteration used
+    // the previous centres and the order the E-step of this iteration used
     float cold_r[RR];
     int spa[RR], spb[RR];
 #pragma unroll
-    for (int r = 0; r < RR; r++) { cold_r[r] = 0.0f; spa[r] = 0; spb[r] = 0; }
-    if (mode != FIN_INIT) {
-        const uint16_t *so_e = ws->tab[cur].perm;
-#pragma unroll
-        for (int r = 0; r < RR; r++) {
-            const int j = tid + r * NT;
-            if (j < k) { cold_r[r] = ws->c[cur][j]; spa[r] = so_e[j]; spb[r] = (j + 1 < k) ? so_e[j + 1] : 0; }
-        }
+    for (int r = 0; r < RR; r++) {
+        const int j = tid + r * NT;
+        const bool in = mode != FIN_INIT && j < k;
+        cold_r[r] = in ? (cur ? c_both[r][1] : c_both[r][0]) : 0.0f;
+        spa[r] = in ? (int)(cur ? pm_both[r][1] : pm_both[r][0]) : 0;
+        spb[r] = (in && j + 1 < k) ? (int)(cur ? pmn_both[r][1] : pmn_both[r][0]) : 0;
+        if (!(track && j < k)) pc[r] = 0;
     }
-    if (mode == FIN_FROM_SHARDS || mode == FIN_PACK_ONLY) {
+    if (from_shards) {
         const KmTab *tab = &ws->tab[cur];
         const int ku_cur = cur ? ku1 : ku0;
         for (int j = tid; j < k; j += NT) { sum_o[j] = 0; cnt_o[j] = 0; } // duplicates of a centre own nothing
         FIN_SYNC();
+        FIN_QUEUE_RESET();
+        FSTAMP(35);
         for (int p = tid; p < ku_cur; p += NT) {
             long long s = 0;
             unsigned long long c = 0;
-            const int o = tab->orig[p];
-            for (int sh = 0; sh < KM_NSHARD; sh++) {
-                s += ws->shard_sum[sh][p]; c += ws->shard_cnt[sh][p];
-                ws->shard_sum[sh][p] = 0; ws->shard_cnt[sh][p] = 0;
+            int o;
+            if (p == tid && sh_pre) { // (the round fetched above)
+                o = cur ? og_both[1] : og_both[0];
+#pragma unroll
+                for (int sh = 0; sh < KM_NSHARD; sh++) { s += sh_s[sh]; c += sh_c[sh]; }
+            } else {
+                o = tab->orig[p];
+                for (int sh = 0; sh < KM_NSHARD; sh++) { s += ws->shard_sum[sh][p]; c += ws->shard_cnt[sh][p]; }
             }
+            for (int sh = 0; sh < KM_NSHARD; sh++) { ws->shard_sum[sh][p] = 0; ws->shard_cnt[sh][p] = 0; }
             sum_o[o] = s; cnt_o[o] = (long long)c;
         }
         FIN_SYNC();
+        FSTAMP(36);
         for (int j = tid; j < k; j += NT) {
             ws->partials[j] = sum_o[j]; ws->partials[k + j] = cnt_o[j];
             ws->partials_local[j] = sum_o[j]; ws->partials_local[k + j] = cnt_o[j];
@@ -1450,6 +1522,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         for (int j = tid; j < k; j += NT) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
     FIN_SYNC();
+    FSTAMP(37);
+    if (!from_shards) FIN_QUEUE_RESET(); // (FIN_INIT: the first pass of a fit starts with an empty queue)
     int same_counts_now = 0;
     bool settled_event = false; // an empty-cluster event was settled in this very call (km_finalize_relocate)
     if (track) {
@@ -1807,6 +1881,8 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     FSTAMP(7);
     if (settled_event && ftr && tid == 0) ftr[26] = ftr[7];
 #undef FSTAMP
+#undef FIN_QUEUE_RESET
+#undef FIN_LEAVE
 #undef FIN_SYNC
 #undef FIN_OR
 #undef FIN_AND
@@ -1858,6 +1934,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
     __shared__ int fin_asked;
     const int tid = threadIdx.x;
     const int cond = lazy & 2; // enqueued behind k_lloyd in case it hands an iteration over (ws->wide): nothing to do otherwise
+    const int k_hint = lazy >> 8; // the number of centres as the launcher knows it (0: not told): bounds the first round of loads
     lazy &= 1;
     if (cond) {
         if (tid == 0) fin_asked = ws->wide;
@@ -1870,7 +1947,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
         if (tid == 0) { fin_go = 0; fin_novf = 0; }
         __syncthreads();
         if (tid < NT) {
-            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n);
+            const bool built = km_finalize_body<NT, FUSED>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n, k_hint);
             if (tid == 0) __hip_atomic_store(&fin_go, (built && !lazy) ? 1 : 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         int go; // every path of the body ends in the store above, so the wait is bounded by the body's run time
@@ -1883,7 +1960,7 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
             if (tid == 0) tab->n_ovf = fin_novf;
         }
     } else {
-        km_finalize_body<NT, false, MASS>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n);
+        km_finalize_body<NT, false, MASS>(ws, mode, resume, gcell, hcell, fin_kc, lazy != 0, reloc_xs, reloc_n, k_hint);
     }
     if (cond && fin_asked) { // the iteration k_lloyd handed over has been run (or has paused): the loop may go on
         __syncthreads();
@@ -2066,8 +2143,8 @@ int km_launch_finalize(KmWs *w, const nnc_kmeans_params *p, int mode, int resume
     nnc_kmeans_status *hs = reinterpret_cast<nnc_kmeans_status *>(hb);
     unsigned long long *ht = reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr);
     nnc_kmeans_status *fs = cells ? nullptr : hs; // the look-in rides on the last launch
-#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0), reloc_xs, (long long)(p ? p->n : 0))
-#define KM_LAUNCH_FIN_MASS(NT, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, false, true>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0), reloc_xs, (long long)(p ? p->n : 0))
+#define KM_LAUNCH_FIN(NT, FUSED, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, FUSED>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0) | (k > 0 ? k << 8 : 0), reloc_xs, (long long)(p ? p->n : 0))
+#define KM_LAUNCH_FIN_MASS(NT, THREADS) NNC_LAUNCH_PROF(NNC_PROF_FINALIZE, (k_finalize<NT, false, true>), dim3(1), dim3(THREADS), 0, S(stream), w, mode, resume, fs, ht, (unsigned long long)ticket, (lazy ? 1 : 0) | (cond ? 2 : 0) | (k > 0 ? k << 8 : 0), reloc_xs, (long long)(p ? p->n : 0))
     const bool mass = p && (p->flags & NNC_KM_MASS_IN_PLACE) && reloc_xs && !fused && k > 64;
     if (fused) KM_LAUNCH_FIN(64, true, KM_THREADS);
     else if (k > 0 && k <= 64) KM_LAUNCH_FIN(64, false, 64);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps of k_finalize (thread 0) for a small-K and the headline fit."""
+"""Phase stamps of k_finalize (thread 0) and of the k_bounds waves (lane 0 of each) for a small-K and the headline fit."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,6 +19,7 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
     tr = torch.zeros(8192, dtype=torch.int64, device=dev)
     acc = []
     late = []
+    bnd = []   # per plain iteration: the k_bounds waves' stamps relative to the first wave's start, and the gap to the finalize step
     for it in range(1, 60):
         tr.zero_()
         if it >= 6:
@@ -28,15 +29,29 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
         torch.cuda.synchronize()
         nat.check(L.nnc_debug_set_trace(0))
         if it >= 6 and not st.paused:
-            t = tr.cpu().numpy()[6 * 1024: 6 * 1024 + 16]
+            full = tr.cpu().numpy()
+            t = full[6 * 1024: 6 * 1024 + 40]
             if t[7] > t[0]:
                 (late if it >= 22 else acc).append((t - t[0]) * 0.01)
+                kb = full[: 16 * 300].reshape(300, 16)[:, :7]
+                kb = kb[(kb[:, 0] > 0) & (kb[:, 6] > 0)]
+                if it >= 22 and len(kb):
+                    t0 = kb[:, 0].min()
+                    rel = (kb - t0) * 0.01
+                    bnd.append(np.concatenate([np.median(rel, axis=0), rel.max(axis=0), [(t[0] - kb[:, 6].max()) * 0.01, (t[0] - t0) * 0.01, len(kb)]]))
         if st.done:
             break
         if st.paused:
             km._relocate_and_resume(st)
     f = np.median(np.array(acc), axis=0)
     print(f"n={n} K={2**bits}: k_finalize stamps, iterations 6-21, median of {len(acc)} (us since start): " + ", ".join(f"{nm} {f[i]:.2f}" for i, nm in order))
+    if bnd:
+        b = np.median(np.array(bnd), axis=0)
+        names = ["start", "zones+phi", "hint round", "searches", "prefix+own", "wave done", "help done"]
+        print(f"n={n}: k_bounds waves, iterations 22-, median over {len(bnd)} passes of (median wave | slowest wave) us since the first wave's start: "
+              + ", ".join(f"{nm} {b[i]:.2f}|{b[7 + i]:.2f}" for i, nm in enumerate(names))
+              + f"; last wave's end -> finalize start {b[14]:.2f}; first wave's start -> finalize start {b[15]:.2f}; waves {b[16]:.0f}")
     if late:
         f = np.median(np.array(late), axis=0)
+        print(f"   inside shards->partials (us since start): header read + queue zeroed {f[34]:.2f}, sums zeroed + barrier {f[35]:.2f}, shards added into LDS + barrier {f[36]:.2f}, partials stored + barrier {f[37]:.2f}")
         print(f"n={n} K={2**bits}: k_finalize stamps, iterations 22-, median of {len(late)} (us since start): " + ", ".join(f"{nm} {f[i]:.2f}" for i, nm in order))
