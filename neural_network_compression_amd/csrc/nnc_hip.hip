@@ -492,6 +492,9 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
 #define KM_PB NNC_PREFIX_BLOCK
 #define KM_PG 1024 // blocks per group of the two-level prefix
 #define KM_TILE 2048
+#ifndef KM_FIT_LAG
+#define KM_FIT_LAG 2 // iterations a plain batch still has to run when its status goes to the host (nnc_kmeans_fit)
+#endif
 #define KM_ZONE_REACH 12 // neighbours either side whose pair with a centre is looked at for its zone (km_finalize_body)
 #define KM_ACC_W 256 // candidates of a crowded stretch whose sums a wave gathers in LDS
 // samples per tile of a long undecided stretch: the work of a tile is samples x candidates, so a stretch many centres compete for
@@ -2552,7 +2555,7 @@ extern "C" int nnc_kmeans_label_counts(const float *x, void *ws, const nnc_kmean
 }
 
 static int km_iterate_publish_(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped, uint64_t ticket, void *stream,
-                               bool reloc_in_place);
+                               bool reloc_in_place, int lag = 0);
 extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped,
                                           uint64_t ticket, void *stream)
 {
@@ -2560,8 +2563,10 @@ extern "C" int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_km
 }
 
 // reloc_in_place: x is the value-sorted vector and the finalize step may settle small empty-cluster events itself
+// lag: the status goes to the host `lag` iterations BEFORE the end of the batch (launch-per-iteration form only), so that the caller
+// can have the next batch enqueued while this one is still running (nnc_kmeans_fit)
 static int km_iterate_publish_(const float *x, void *ws, const nnc_kmeans_params *pp, int32_t iters, void *host_mapped, uint64_t ticket, void *stream,
-                               bool reloc_in_place)
+                               bool reloc_in_place, int lag)
 {
     int rc = km_check(ws, pp, "nnc_kmeans_iterate_publish");
     if (rc) return rc;
@@ -2588,7 +2593,7 @@ static int km_iterate_publish_(const float *x, void *ws, const nnc_kmeans_params
     }
     for (int i = 0; i < iters; i++) {
         if ((rc = km_launch_accumulate(x, w, &p, stream))) return rc;
-        const bool last = i == iters - 1;
+        const bool last = i == std::max(0, (int)iters - 1 - lag);
         if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream, last ? host_mapped : nullptr, ticket, false,
                                      (reloc_in_place && p.prefix_dev) ? x : nullptr))) return rc;
     }
@@ -3660,7 +3665,15 @@ extern "C" int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_pa
                 if ((rc = km_launch_finalize(w, &p, FIN_FROM_SHARDS, 0, stream, nullptr, 0, false, x_iter))) return rc; // (small events: in place)
                 if ((rc = km_launch_spec_reloc(x_iter, w, &p, reloc_scratch_dev, stream, i == batch - 1 ? sl : nullptr, ticket))) return rc;
             }
-        } else if ((rc = km_iterate_publish_(x_iter, ws, &p, batch, sl, ticket, stream, spec_ok))) return rc;
+        } else {
+            // The status of a plain batch leaves two iterations before its end: the round trip to the host and the enqueuing of the
+            // next batch (8-13 us, seven to nine times a fit) then happen while those two are running, not on an idle GPU.  What the
+            // host has not seen yet costs nothing but launches: every kernel of an iteration looks at the status itself and returns
+            // at once when the fit is over or has paused, so a batch enqueued behind a convergence the host learns of a look-in
+            // later is a row of no-ops; the trajectory is the device's alone.
+            const int lag = (!one_launch && batch >= 4) ? KM_FIT_LAG : 0;
+            if ((rc = km_iterate_publish_(x_iter, ws, &p, batch, sl, ticket, stream, spec_ok, lag))) return rc;
+        }
         if ((rc = km_wait_ticket(reinterpret_cast<volatile unsigned long long *>(sl + sizeof(nnc_kmeans_status)), ticket, S(stream)))) return rc;
         const nnc_kmeans_status st = *reinterpret_cast<const nnc_kmeans_status *>(sl);
         *status_out = st;

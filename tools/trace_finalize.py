@@ -33,8 +33,9 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
             t = full[6 * 1024: 6 * 1024 + 40]
             if t[7] > t[0]:
                 (late if it >= 22 else acc).append((t - t[0]) * 0.01)
-                kb = full[: 16 * 300].reshape(300, 16)[:, :7]
-                kb = kb[(kb[:, 0] > 0) & (kb[:, 6] > 0)]
+                kball = full[: 16 * 300].reshape(300, 16)
+                live = (kball[:, 0] > 0) & (kball[:, 6] > 0)
+                kb = kball[live][:, :7]
                 if it >= 22 and len(kb):
                     t0 = kb[:, 0].min()
                     rel = (kb - t0) * 0.01
