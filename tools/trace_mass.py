@@ -34,3 +34,10 @@ for o in range(16):
     N, ms = int(s[8]) >> 32, int(s[8]) & 0xFFFFFFFF
     done = s[7] > 0
     print(f"  mass event #{o}: m = {int(s[9])}, {N} candidate keys in the first turn, {ms} ends into the second; " + (", ".join(f"{nm} {v:.1f}" for nm, v in zip(names, d)) if done else "not settled (phases reached: " + ", ".join(f"{nm} {v:.1f}" for nm, v in zip(names, d) if v > 0) + ")"))
+# the LAST event the finalize step settled in place (the stamps of later launches do not touch these slots): phases since the launch's start
+if t[22] > 0:
+    z = float(t[20])
+    r = (t[30:38].astype(np.float64) - z) * 0.01
+    print(f"last event settled in place: selection starts {(t[21] - z) * 0.01:.1f}, certain ends {r[1]:.1f}, undecided samples {r[2]:.1f}, barrier {r[3]:.1f}, keys in registers {r[4]:.1f}, "
+          f"rounds {r[5]:.1f}, proof + empties {r[6]:.1f}, old clusters + edits {r[7]:.1f}, selection done {(t[22] - z) * 0.01:.1f}; shift / tolerance {(t[23] - z) * 0.01:.1f}, centres sorted {(t[24] - z) * 0.01:.1f}, "
+          f"zones {(t[25] - z) * 0.01:.1f}, end {(t[26] - z) * 0.01:.1f} us")
