@@ -218,7 +218,8 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
     unsigned char *wb = reinterpret_cast<unsigned char *>((reinterpret_cast<uintptr_t>(ws_dev) + 255) & ~(uintptr_t)255);
     unsigned char *hb = reinterpret_cast<unsigned char *>(host_pinned);
     // host block: [0, 504) the fit's two status slots; 504 the ticket of this call's own reads; [512, 576) a mirror of the
-    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed), [576, 840) the ranks behind it; [896, 1024) the 32 histogram
+    // device's scalar block (out6 | signs[2] | prune {sigma, threshold} | nzeroed), [576, 840) the ranks behind it; 864 the ticket and 872 the two floats of the read that
+    // travels on the second stream (mean, variance); [896, 1024) the 32 histogram
     // steps (read from here by the rank kernel); [1024, ...) the K-sized read at the end.  A read = one small launch that copies into the block and
     // writes a ticket behind the bytes; the thread spins on the ticket (nnc_kmeans_status_publish's way).
     const float *h_f = reinterpret_cast<const float *>(hb + 512);                // out6
@@ -312,6 +313,14 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         LCHK(nnc_fold_f32(c1, nch, n, NNC_FOLD_MEAN, nullptr, out6, side->stream));           // [0] = mean
         LCHK(nnc_chunk_sums_f32(x, n, 1, out6, c2, side->stream));
         LCHK(nnc_fold_f32(c2, nch, n, NNC_FOLD_MEAN, nullptr, out6 + 1, side->stream));       // [1] = variance
+        // ... and go to the host from there, as soon as they exist (the sort is still running on the caller's stream): the fit's
+        // parameters are then known and the prefix sums can be enqueued right behind the sort, in front of the round trip that
+        // fetches the ranks for the initial centres -- the device builds the prefixes while the host works out the centres
+        // (until round 4 both waited for one read behind the sort: 25-70 us of idle device per layer)
+        void *h_ticket_side = hb + 864;
+        const float *h_mv = reinterpret_cast<const float *>(hb + 872);
+        const uint64_t t_mv = ++(*ticket_io);
+        LCHK(nnc_publish_bytes_(out6, hb + 872, 8, h_ticket_side, t_mv, side->stream));
         LHIP(hipEventRecord(side->join, side->stream));
         float *xs = reinterpret_cast<float *>(wb + L.sorted);
         int32_t *oob_d = reinterpret_cast<int32_t *>(wb + L.stats_out + 336); // the bounded sort's verdict: a weight outside the bounds it was given
@@ -340,24 +349,20 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
             std::memcpy(h_steps, steps, 128); // (read by the kernel straight from the pinned block)
             LCHK(nnc_rank_sorted_f32(xs, n, h_steps, 32, ranks_d, stream));
         }
-        // ---- the second read: mean, variance (and the ranks)
+        // ---- the second read (enqueued, not waited for yet): min / max, signs, the ranks, the sort's verdict
+        const uint64_t t_rk = ++(*ticket_io);
+        LCHK(nnc_publish_bytes_(out6 + 2, hb + 512 + 8, 56 + 33 * 8 + 16, h_ticket, t_rk, stream));
+        LCHK(nnc_wait_ticket_(h_ticket_side, t_mv, side->stream));
         LHIP(hipStreamWaitEvent(s, side->join, 0));
         side_join.joined = true;
-        LCHK(read_back(out6, hb + 512, 64 + 33 * 8 + 16));
-        if (!std::isfinite(h_f[0]) || !std::isfinite(h_f[1]) || !std::isfinite(xmin) || !std::isfinite(xmax)) {
+        const float mean = h_mv[0], var = h_mv[1];
+        if (!std::isfinite(mean) || !std::isfinite(var) || !std::isfinite(xmin) || !std::isfinite(xmax)) {
             // a NaN or an infinity in the tensor: KMeans.fit raises on such input, and so does the caller's own path (from the pruned tensor)
+            LCHK(nnc_wait_ticket_(h_ticket, t_rk, stream));
             if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
             res->status = NNC_LAYER_HOST;
             return NNC_OK;
         }
-        if (bounded && *h_oob) {
-            // a weight outside [min, -threshold] u {0} u [threshold, max] -- a NaN, the statistics pass ignores those: the compact-key
-            // sort clamped it, so the sorted copy is not the tensor's.  The step-by-step path (general sorts) goes on from here.
-            if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
-            res->status = NNC_LAYER_HOST;
-            return NNC_OK;
-        }
-        const float mean = h_f[0], var = h_f[1];
         // ---- k-means parameters (KMeans.fit's tolerance and centring, _kmeans.py:279-287, 1479-1484; the fixed-point rule)
         nnc_kmeans_params p;
         std::memset(&p, 0, sizeof(p));
@@ -367,6 +372,21 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         p.fix_shift = nnc_fix_shift(std::max(std::fabs((float)lo), std::fabs((float)hi)), n);
         p.grid_log2 = 0; p.replicas_log2 = -1; p.flags = lp->km_flags & (NNC_KM_TWO_LAUNCH | NNC_KM_LOOP);
         p.x_mean = mean; p.tol = tol; p.lo = lo; p.hi = hi;
+        // the prefix sums of the sorted copy: behind the sort on the caller's stream, while the ranks travel
+        // (the pointer is set before the fit is initialised: its first finalize step then knows that the iterations will not read the
+        // cell table and leaves it to the labelling pass at the end -- one launch of k_cells less)
+        if (with_prefix) {
+            LCHK(nnc_kmeans_prefix_build(xs, &p, reinterpret_cast<int64_t *>(wb + L.prefix), stream));
+            p.prefix_dev = reinterpret_cast<int64_t *>(wb + L.prefix);
+        }
+        LCHK(nnc_wait_ticket_(h_ticket, t_rk, stream));
+        if (bounded && *h_oob) {
+            // a weight outside [min, -threshold] u {0} u [threshold, max] -- a NaN, the statistics pass ignores those: the compact-key
+            // sort clamped it, so the sorted copy is not the tensor's.  The step-by-step path (general sorts) goes on from here.
+            if (lp->prune) { res->sigma = h_prune[0]; res->threshold = h_prune[1]; res->n_zeroed = h_nz[0]; }
+            res->status = NNC_LAYER_HOST;
+            return NNC_OK;
+        }
         // ---- initial centroids (utility.py:206-226)
         if (lp->mode == NNC_INIT_LINEAR) {
             LCHK(nnc_host_linspace_f32(xmin, xmax, k, space));
@@ -382,10 +402,6 @@ extern "C" int nnc_compress_layer_f32(float *x, int64_t n, const nnc_layer_param
         }
         std::memcpy(h_space, space, (size_t)k * 4);
         LCHK(nnc_kmeans_init(wb + L.km_ws, L.km_ws_bytes, &p, h_space, stream));
-        if (with_prefix) {
-            LCHK(nnc_kmeans_prefix_build(xs, &p, reinterpret_cast<int64_t *>(wb + L.prefix), stream));
-            p.prefix_dev = reinterpret_cast<int64_t *>(wb + L.prefix);
-        }
         // ---- the Lloyd loop
         nnc_kmeans_status st;
         std::memset(&st, 0, sizeof(st));
