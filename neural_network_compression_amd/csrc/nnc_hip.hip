@@ -502,6 +502,9 @@ __global__ __launch_bounds__(KM_THREADS, 8) void k_assign(const float *__restric
 // tiles of 2048) is cut finer -- KM_TILE for two candidates, 64 samples for sixty-four and more
 __host__ __device__ __forceinline__ int km_tile_len(int ncand) { int t = (2 * KM_TILE / (ncand < 2 ? 2 : ncand)) & ~63; return t < 64 ? 64 : t; }
 #define KM_Q_VALID (1ull << 62)
+#ifndef KM_PUBLISH_TILES
+#define KM_PUBLISH_TILES 5 // an undecided stretch of more tiles than this goes to the queue; a shorter one is its wave's own work
+#endif
 
 
 // Wave-wide reductions whose result every lane needs, without the LDS crossbar: __shfl_xor is ds_bpermute_b32 here -- a trip through
@@ -642,25 +645,26 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
                                                         KmWs *ws, float mean, int Sft, int lane)
 {
     s = uni_ll(s); e = uni_ll(e); plo = uni_i(plo); phi = uni_i(phi);
-    if (e - s >= 128 && phi > plo) {
-        // A run of EQUAL values -- the zeros of a pruned vector between two centres float32 cannot tell apart: 17 M samples of the
-        // bench vector, twice per fit -- gets one label: the vector is sorted, so equal ends mean equal everything in between.
-        // One evaluation (the general rule: first strict minimum, ties to the lowest original index), value x count.
-        const float x0 = xs[s], x1 = xs[e - 1];
-        if (x0 == x1) {
-            const float xc = x0 - mean;
-            float bestd = INFINITY;
-            int best = plo, besto = 0x7fffffff;
-            for (int c = plo; c <= phi; c++) { // (wave-uniform: scalar loads)
-                const float2 cm = tab->cand[c];
-                const int oc = (int)tab->orig[c];
-                const float d = cm.y + (-2.0f * (xc * cm.x));
-                if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = c; besto = oc; }
-            }
-            if (lane == 0) km_shard_add(ws, best, (long long)fix_f32(xc, Sft) * (e - s), (unsigned long long)(e - s));
-            return;
+    // A run of EQUAL values -- the zeros of a pruned vector between two centres float32 cannot tell apart: 17 M samples of the
+    // bench vector, twice per fit -- gets one label: the vector is sorted, so equal ends mean equal everything in between.
+    // One evaluation (the general rule: first strict minimum, ties to the lowest original index), value x count.
+    // (The two ends are asked for here and looked at below, behind the loads of the path taken: a helper that waited for them
+    // first, then for the two centres, then for its samples was three round trips from its first sum.)
+    const bool chk = e - s >= 128 && phi > plo;
+    float x0 = 0.0f, x1 = 1.0f;
+    if (chk) { x0 = xs[s]; x1 = xs[e - 1]; }
+    auto flat_run = [&]() {
+        const float xc = x0 - mean;
+        float bestd = INFINITY;
+        int best = plo, besto = 0x7fffffff;
+        for (int c = plo; c <= phi; c++) { // (wave-uniform: scalar loads)
+            const float2 cm = tab->cand[c];
+            const int oc = (int)tab->orig[c];
+            const float d = cm.y + (-2.0f * (xc * cm.x));
+            if (d < bestd || (d == bestd && oc < besto)) { bestd = d; best = c; besto = oc; }
         }
-    }
+        if (lane == 0) km_shard_add(ws, best, (long long)fix_f32(xc, Sft) * (e - s), (unsigned long long)(e - s));
+    };
     if (phi <= plo) { // (cannot happen for an undecided stretch; kept total: everything is plo's)
         long long sum = 0;
         unsigned cnt = 0;
@@ -678,10 +682,15 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
         // sixteen loads in flight per lane: a wave that is left alone with the tiles of a long stretch (its helpers looked at the
         // queue before the record was out) is bound by the latency of these loads -- with four in flight a tile of 2048 samples took
         // 8 us and the 75 tiles of one record of the bench fit 600 us whenever nobody came
-        for (long long i0 = s; i0 < e; i0 += 1024) {
-            float v[16];
+        float v[16];
 #pragma unroll
-            for (int u = 0; u < 16; u++) { const long long i = i0 + lane + 64 * u; v[u] = i < e ? xs[i] : 0.0f; }
+        for (int u = 0; u < 16; u++) { const long long i = s + lane + 64 * u; v[u] = i < e ? xs[i] : 0.0f; }
+        if (chk && x0 == x1) { flat_run(); return; }
+        for (long long i0 = s; i0 < e; i0 += 1024) {
+            if (i0 > s) {
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const long long i = i0 + lane + 64 * u; v[u] = i < e ? xs[i] : 0.0f; }
+            }
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const long long i = i0 + lane + 64 * u;
@@ -699,6 +708,7 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
         if (lane == 0) { km_shard_add(ws, plo, s0, (unsigned long long)m0); km_shard_add(ws, plo + 1, s1, (unsigned long long)m1); }
         return;
     }
+    if (chk && x0 == x1) { flat_run(); return; }
     // three or more centres within rounding distance of each other: the general scan.  The candidates sit in the lanes'
     // registers (lane l holds centre g0 + l of the current group of 64) and go round by readlane; a lane takes four samples
     // per batch so that their loads are in flight together and every candidate is fetched once for the four.  Where float32
@@ -722,51 +732,58 @@ __device__ __forceinline__ void km_bounds_range(const float *__restrict__ xs, lo
     const bool one_group = ncand <= 64; // the candidates stay in the lanes' registers over the whole call
     if (one_group && lane < ncand) { cm0 = tab->cand[plo + lane]; om0 = (int)tab->orig[plo + lane]; }
     wave_lds_fence();
-    for (long long i0 = s; i0 < e; i0 += 256) {
-        float xc[4], bestd[4];
-        int best[4], besto[4];
-        bool have[4];
+    // (NU samples a lane and batch: four where the stretch is longer than a wave -- every candidate fetched once for the four --, one
+    // for a tile of 64 samples, the tile length of a crowd: the unrolled four cost a 64-sample tile of 51 candidates 2200
+    // instructions, three quarters of them for samples that are not there, and a lone wave issues one instruction in four clocks)
+    auto scan = [&](auto nu_c) {
+        constexpr int NU = decltype(nu_c)::value;
+        for (long long i0 = s; i0 < e; i0 += 64 * NU) {
+            float xc[NU], bestd[NU];
+            int best[NU], besto[NU];
+            bool have[NU];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const long long i = i0 + lane + 64 * u;
-            have[u] = i < e;
-            xc[u] = have[u] ? xs[i] - mean : 0.0f;
-            bestd[u] = INFINITY; best[u] = plo; besto[u] = 0x7fffffff;
-        }
-        for (int g0 = plo; g0 <= phi; g0 += 64) {
-            float2 cm = cm0;
-            int om = om0;
-            if (!one_group) {
-                const int mine = g0 + lane;
-                cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
-                om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
+            for (int u = 0; u < NU; u++) {
+                const long long i = i0 + lane + 64 * u;
+                have[u] = i < e;
+                xc[u] = have[u] ? xs[i] - mean : 0.0f;
+                bestd[u] = INFINITY; best[u] = plo; besto[u] = 0x7fffffff;
             }
-            const int cnt = min(64, phi - g0 + 1);
-            for (int c = 0; c < cnt; c++) {
-                const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.x), c));
-                const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.y), c));
-                const int oc = __builtin_amdgcn_readlane(om, c);
+            for (int g0 = plo; g0 <= phi; g0 += 64) {
+                float2 cm = cm0;
+                int om = om0;
+                if (!one_group) {
+                    const int mine = g0 + lane;
+                    cm = mine <= phi ? tab->cand[mine] : make_float2(0.0f, 0.0f);
+                    om = mine <= phi ? (int)tab->orig[mine] : 0x7fffffff;
+                }
+                const int cnt = min(64, phi - g0 + 1);
+                for (int c = 0; c < cnt; c++) {
+                    const float cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.x), c));
+                    const float cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cm.y), c));
+                    const int oc = __builtin_amdgcn_readlane(om, c);
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float d = cy + (-2.0f * (xc[u] * cx));
-                    if (d < bestd[u] || (d == bestd[u] && oc < besto[u])) { bestd[u] = d; best[u] = g0 + c; besto[u] = oc; }
+                    for (int u = 0; u < NU; u++) {
+                        const float d = cy + (-2.0f * (xc[u] * cx));
+                        if (d < bestd[u] || (d == bestd[u] && oc < besto[u])) { bestd[u] = d; best[u] = g0 + c; besto[u] = oc; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+                if (have[u]) {
+                    if (use_lds) {
+                        atomicAdd(&acc_sum[wv][best[u] - plo], (unsigned long long)(long long)fix_f32(xc[u], Sft));
+                        atomicAdd(&acc_cnt[wv][best[u] - plo], 1u);
+                    } else {
+                        if (best[u] != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best[u]; run_n = 0; run_s = 0; }
+                        run_n++;
+                        run_s += fix_f32(xc[u], Sft);
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (have[u]) {
-                if (use_lds) {
-                    atomicAdd(&acc_sum[wv][best[u] - plo], (unsigned long long)(long long)fix_f32(xc[u], Sft));
-                    atomicAdd(&acc_cnt[wv][best[u] - plo], 1u);
-                } else {
-                    if (best[u] != run_p) { if (run_n) km_shard_add(ws, run_p, run_s, run_n); run_p = best[u]; run_n = 0; run_s = 0; }
-                    run_n++;
-                    run_s += fix_f32(xc[u], Sft);
-                }
-            }
-        }
-    }
+    };
+    if (e - s <= 64) scan(std::integral_constant<int, 1>{}); else scan(std::integral_constant<int, 4>{});
     if (use_lds) {
         wave_lds_fence();
         for (int c = lane; c < ncand; c += 64) if (acc_cnt[wv][c]) km_shard_add(ws, plo + c, (long long)acc_sum[wv][c], (unsigned long long)acc_cnt[wv][c]);
@@ -824,7 +841,8 @@ __device__ __forceinline__ void km_bounds_preload(KmBndPre<BR> &p, const int j, 
 template <int BR>
 __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, const float *__restrict__ xs, const long long n, KmWs *__restrict__ ws,
                                                const KmTab *__restrict__ tab, const KmBndSrc src, const float mean, const int Sft,
-                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> &pre, const int announced = 0)
+                                               const long long *__restrict__ pblk, int *qn_seen, const KmBndPre<BR> &pre, const int announced = 0,
+                                               int *wg_searched = nullptr)
 {
     bool published = false;
     // ---- one round of loads: every zone end (a lane holds those of the centres lane, lane + 64, ...; bounded by the caller's k,
@@ -949,7 +967,11 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
         // (a long stretch of one value -- the zero plateau -- is no work at all: km_bounds_range settles it with one evaluation)
         const int tile = km_tile_len(phi - j + 1);
         const bool flat = und > tile && xs[s] == xs[b - 1];
-        if (und > tile && !flat) {
+        // (a crowd's stretch from six tiles up: a helper is three dependent round trips away from its first sample -- the records, the claim, the samples --,
+        // some 8 us in a pass where everybody is at the queue; the publisher is through five tiles of its own in less)
+        // (... where its samples are few: a wave on its own has 256 samples in flight at a time, a round trip each)
+        const int self_max = max(tile, min(1024, KM_PUBLISH_TILES * tile));
+        if (und > self_max && !flat) {
             const int r = km_claim(&ws->q_n, lane);
             if (r < NNC_KMAX) { // (every wave publishes at most once per launch and there are at most NNC_KMAX waves)
                 published = true;
@@ -962,7 +984,15 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
         // (an announced pass: the others wait at the queue until every wave has said whether it had something to publish.
         // Relaxed: a release at agent scope writes this XCD's L2 back -- measured 8 us a wave; the record above went out as atomic
         // stores in front of this one, and a helper that should still miss it costs nothing but its help)
-        if (announced && lane == 0) __hip_atomic_fetch_add(&ws->q_searched, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (one atomic a WORKGROUP, by the last of its waves to get here -- they count in LDS first: 257 atomics on one word queued up at
+        // the memory side, and memory operations return in order: every wave's next load waited behind its own increment, the own work
+        // of a wave in an announced pass took 13 us against 8.5)
+        if (announced) {
+            const int mine = min(4, ku - 4 * (int)blockIdx.x); // waves of this workgroup that have a boundary (j < ku)
+            int last = 0;
+            if (lane == 0) last = atomicAdd(wg_searched, 1) + 1 == mine;
+            if (uni_i(last) && lane == 0) __hip_atomic_fetch_add(&ws->q_searched, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         float uv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         if (quick) {
 #pragma unroll
@@ -1000,29 +1030,43 @@ __device__ __forceinline__ bool km_bounds_wave(const int j, const int lane, cons
 // Tiles of long undecided stretches: every wave of the launch that comes through here takes tiles from the records that are out.
 // A publisher comes through here after its own record is out and leaves only when all its tiles are taken, so no tile depends on
 // anybody else (nobody waits for anybody: a record a wave does not see yet is finished by its publisher).
+// (myj / nwaves: the caller's boundary and the number of waves of its pass that come through here, if it knows them.  A record with
+// few tiles left is then approached by about that many waves, not by all of them: a claim is an atomic on ONE word at the memory
+// side, and 260 of them for a record of five tiles -- every wave of an announced pass arrives at the same moment -- queued up for
+// 10-20 us, most of what the passes behind a placement cost.  The publisher always sees to its own record.)
 __device__ __forceinline__ void km_bounds_help(const int lane, const float *__restrict__ xs, KmWs *__restrict__ ws,
-                                               const KmTab *__restrict__ tab, const float mean, const int Sft)
+                                               const KmTab *__restrict__ tab, const float mean, const int Sft, const int myj = -1, const int nwaves = 0)
 {
     // (relaxed on purpose: an acquire per look would drop the caches of a thousand waves)
     // Sixty-four records a look: lane r reads record r, so a walk through the queue is one round trip to the memory side, not one
     // per record (with a few dozen records out -- the iterations right after a mass relocation -- every wave of the launch used
     // to spend its hundred microseconds walking, whatever there was left to do).
-    const int nrec = min(km_peek_i(&ws->q_n), (int)NNC_KMAX);
+    // (the first sixty-four records are fetched together with the counter, not behind it: a slot nobody has written holds no VALID
+    // bit -- the finalize step clears what a pass has used -- so the counter only says whether there is a second round)
+    int nrec = 64;
     for (int r0 = 0; r0 < nrec; r0 += 64) {
         const int rl = r0 + lane;
         unsigned long long w0 = 0ull, w1 = 0ull;
         int nx = 0x7fffffff;
-        if (rl < nrec) {
+        if (rl < NNC_KMAX) {
             w0 = __hip_atomic_load(&ws->q_w0[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             w1 = __hip_atomic_load(&ws->q_w1[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             nx = __hip_atomic_load(&ws->q_next[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (r0 == 0) nrec = min(km_peek_i(&ws->q_n), (int)NNC_KMAX);
+        if (rl >= nrec) { w0 = 0ull; w1 = 0ull; }
         bool live = false;
         if ((w0 & KM_Q_VALID) && (w1 & KM_Q_VALID)) { // (else not out yet: its publisher will see to it)
             const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
             const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
             const int tile = km_tile_len(phi - plo + 1);
-            live = nx < (int)((e - s + tile - 1) / tile); // (spent records: no need to bump their counters again)
+            const int ntl = (int)((e - s + tile - 1) / tile);
+            live = nx < ntl; // (spent records: no need to bump their counters again)
+            if (live && nwaves > 0 && plo != myj) {
+                const int left = ntl - nx; // (as of this look; two claimers a tile: a wave asks for its next tile while it works on one)
+                const int stride = nwaves / (2 * left);
+                if (stride > 1 && (unsigned)(myj + 7 * rl) % (unsigned)stride != 0u) live = false;
+            }
         }
         unsigned long long todo = __ballot(live);
         while (todo) {
@@ -1052,6 +1096,10 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
 {
     const int lane = threadIdx.x & 63;
     const int j = uni_i(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const unsigned long long t_enter = __builtin_amdgcn_s_memrealtime(); // (100 MHz)
+    __shared__ int wg_searched; // waves of this workgroup that are through their searches (an announced pass counts them here first)
+    if (threadIdx.x == 0) wg_searched = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // (LDS only: the loads below do not wait for it; every wave passes here, the early returns are further down)
     KBSTAMP(16 * j + 0, 0);
     KmBndSrc src;
     const KmTab *tab;
@@ -1073,7 +1121,7 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     if (stop | unasked) return;
     int qn_seen = 0; // the number of long stretches that were out when this wave's own loads went out
     if (!fixed_src) km_bounds_preload<BR>(pre, j, lane, ws, src);
-    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, pre, hint == 2);
+    const bool published = km_bounds_wave<BR>(j, lane, xs, n, ws, tab, src, mean, Sft, pblk, &qn_seen, pre, hint == 2, &wg_searched);
     KBSTAMP(16 * j + 5, 0);
     // A look at the queue costs a round trip to the memory side (the counter is shared by all XCDs).  Worth it for the waves of a
     // pass whose predecessor published long stretches (centres stay crowded for a few iterations), and for a publisher: it has
@@ -1086,14 +1134,22 @@ __global__ __launch_bounds__(256) void k_bounds(const float *__restrict__ xs, lo
     // PROGRESS depends on this -- a publisher sees its own tiles through alone if need be -- and the number of looks is bounded,
     // so the loop ends whatever the others do.  Cost: the pass lasts as long as its slowest search plus one look (+ 4 us).
     const bool waits = hint == 2 && !published && fixed_src;
+    int looks = 0;
     if (waits) {
+        // (the first look when the slowest searches of such a pass are about through, 9 us after this wave started, not at once: 260
+        // waves asking one word a million times a second each were in the way of the waves still searching -- their own work took
+        // 13.7 us against 8.5 in a pass nobody polls)
         const int nwaves = pre.ku;
+        for (int nap = 0; nap < 64 && __builtin_amdgcn_s_memrealtime() - t_enter < 900ull; nap++) __builtin_amdgcn_s_sleep(16);
         for (int look = 0; look < 128; look++) {
+            looks++;
             if (km_peek_i(&ws->q_searched) >= nwaves) break;
-            __builtin_amdgcn_s_sleep(32);
+            __builtin_amdgcn_s_sleep(48);
         }
     }
-    if (published || hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft);
+    KBSTAMP(16 * j + 7, 0);
+    if (NNC_KM_TRACE_PTR && lane == 0) NNC_KM_TRACE_PTR[16 * j + 12] = (unsigned long long)looks;
+    if (published || hint || uni_i(qn_seen) > 0) km_bounds_help(lane, xs, ws, tab, mean, Sft, j, hint == 2 ? pre.ku : 0);
     KBSTAMP(16 * j + 6, 0);
 }
 

@@ -22,12 +22,29 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
     bnd = []   # per plain iteration: the k_bounds waves' stamps relative to the first wave's start, and the gap to the finalize step
     for it in range(1, 60):
         tr.zero_()
-        if it >= 6:
+        if it >= 1:
             nat.check(L.nnc_debug_set_trace(tr.data_ptr()))
         km.iterate(1)
         st = km.status()
         torch.cuda.synchronize()
         nat.check(L.nnc_debug_set_trace(0))
+        if 1 <= it <= 14 and n > 20_000_000:   # the passes behind the placements of the first iterations: what their slowest waves did
+            full = tr.cpu().numpy()
+            kball = full[: 16 * 300].reshape(300, 16)
+            live = (kball[:, 0] > 0) & (kball[:, 6] > 0)
+            if live.any():
+                kb = kball[live].astype(np.float64)
+                t0 = kb[:, 0].min()
+                end = (kb[:, 6] - t0) * 0.01
+                order_ = np.argsort(-end)[:3]
+                desc = []
+                for o in order_:
+                    r = (kb[o, :8] - t0) * 0.01
+                    desc.append(f"[start {r[0]:.1f} zones {r[1]:.1f} hint {r[2]:.1f} search {r[3]:.1f} prefix {r[4]:.1f} own {r[5]:.1f} waited {r[7]:.1f} ({int(kb[o, 12])} looks) help {r[6]:.1f}; undecided {int(kb[o, 8])}, candidates {int(kb[o, 9]) + 1}]")
+                und = kb[:, 8]
+                w7 = (kb[:, 7] - t0) * 0.01
+                print(f"   pass {it}: {int(live.sum())} waves, pass ends {end.max():.1f} us after its first wave starts (median wave {np.median(end):.1f}; own work done: median {np.median((kb[:, 5] - t0) * 0.01):.1f}, last {((kb[:, 5] - t0) * 0.01).max():.1f}; wait over: median {np.median(w7):.1f}, last {w7.max():.1f}; looks: median {int(np.median(kb[:, 12]))}, most {int(kb[:, 12].max())}); undecided samples {int(und.sum())} (largest {int(und.max())}, "
+                      f"waves with more than 256: {int((und > 256).sum())}, more than 2048: {int((und > 2048).sum())}), most candidates {int(kb[:, 9].max()) + 1}; slowest waves: " + " ".join(desc))
         if it >= 6 and not st.paused:
             full = tr.cpu().numpy()
             t = full[6 * 1024: 6 * 1024 + 40]
