@@ -1055,7 +1055,7 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
         }
         if (r0 == 0) nrec = min(km_peek_i(&ws->q_n), (int)NNC_KMAX);
         if (rl >= nrec) { w0 = 0ull; w1 = 0ull; }
-        bool live = false;
+        bool live = false, solo = false;
         if ((w0 & KM_Q_VALID) && (w1 & KM_Q_VALID)) { // (else not out yet: its publisher will see to it)
             const long long s = (long long)(w0 & ((1ull << 40) - 1)), e = (long long)(w1 & ((1ull << 40) - 1));
             const int plo = (int)((w0 >> 40) & 0xFFFFF), phi = (int)((w1 >> 40) & 0xFFFFF);
@@ -1063,12 +1063,22 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
             const int ntl = (int)((e - s + tile - 1) / tile);
             live = nx < ntl; // (spent records: no need to bump their counters again)
             if (live && nwaves > 0 && plo != myj) {
-                const int left = ntl - nx; // (as of this look; two claimers a tile: a wave asks for its next tile while it works on one)
-                const int stride = nwaves / (2 * left);
-                if (stride > 1 && (unsigned)(myj + 7 * rl) % (unsigned)stride != 0u) live = false;
+                // (as of this look: with fewer tiles left than waves around, a tile a wave and one claim each -- asking for the next
+                // tile while working on one doubles the atomics, and for most of them the answer is "none left")
+                const int left = ntl - nx;
+#ifdef KM_NO_SOLO
+                if (false) {
+#else
+                if (left <= nwaves) {
+#endif
+                    solo = true;
+                    const int stride = nwaves / left;
+                    if (stride > 1 && (unsigned)(myj + 7 * rl) % (unsigned)stride != 0u) live = false;
+                }
             }
         }
         unsigned long long todo = __ballot(live);
+        const unsigned long long solo_mask = __ballot(live && solo);
         while (todo) {
             const int b = __ffsll((long long)todo) - 1;
             todo &= todo - 1ull;
@@ -1078,6 +1088,13 @@ __device__ __forceinline__ void km_bounds_help(const int lane, const float *__re
             const int tile = km_tile_len(phi - plo + 1);
             const int ntiles = (int)((e - s + tile - 1) / tile);
             int t = km_claim(&ws->q_next[r0 + b], lane);
+            if ((solo_mask >> b) & 1ull) { // (wave-uniform)
+                if (t < ntiles) {
+                    const long long ts = s + (long long)t * tile;
+                    km_bounds_range(xs, ts, ts + tile < e ? ts + tile : e, plo, phi, tab, ws, mean, Sft, lane);
+                }
+                continue;
+            }
             while (t < ntiles) {
                 const int tn = km_claim(&ws->q_next[r0 + b], lane); // (the next ticket is on its way while this tile is worked on: a
                                                                     // wave left alone with a record is otherwise bound by the round trips)
