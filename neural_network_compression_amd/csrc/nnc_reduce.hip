@@ -134,10 +134,14 @@ extern "C" int nnc_chunk_sums_f32(const float *x, int64_t n, int sqdev, const fl
 // whole cost (one add per chunk sum, nothing to parallelise); one lane runs it out of LDS with
 // 16-byte reads issued well ahead, the others stage the next tile.
 #define FOLD_TILE 8192
+// (scale_val / zero64: round 4 -- the factor as an argument and a counter of the NEXT pass zeroed on the way, where the caller used
+// to spend a launch each on parking the factor in device memory and on a memset)
 __global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks, int64_t nchunks, int64_t count,
                                                int op, const float *__restrict__ scale_dev,
-                                               float *__restrict__ out)
+                                               float *__restrict__ out, float scale_val = 0.0f, int has_scale_val = 0,
+                                               unsigned long long *__restrict__ zero64 = nullptr)
 {
+    if (zero64 && threadIdx.x == 0) *zero64 = 0ull;
     __shared__ __align__(16) float buf[FOLD_TILE];
     float acc = 0.0f;
     for (int64_t base = 0; base < nchunks; base += FOLD_TILE) {
@@ -166,6 +170,7 @@ __global__ __launch_bounds__(1024) void k_fold(const float *__restrict__ chunks,
         if (op == NNC_FOLD_STD) r = (float)sqrt((double)r); // double sqrt then round == correctly rounded sqrtf
         out[0] = r;
         if (scale_dev) out[1] = r * (*scale_dev);
+        else if (has_scale_val) out[1] = r * scale_val;
     }
 }
 
@@ -174,7 +179,7 @@ extern "C" int nnc_fold_f32(const float *chunks, int64_t nchunks, int64_t count,
 {
     if (!out_dev || nchunks < 0 || (nchunks > 0 && !chunks)) return fail(NNC_EINVAL, "nnc_fold_f32: bad argument");
     if ((op == NNC_FOLD_MEAN || op == NNC_FOLD_STD) && count <= 0) return fail(NNC_EINVAL, "nnc_fold_f32: count <= 0");
-    hipLaunchKernelGGL(k_fold, dim3(1), dim3(1024), 0, S(stream), chunks, nchunks, count, op, scale_dev, out_dev);
+    hipLaunchKernelGGL(k_fold, dim3(1), dim3(1024), 0, S(stream), chunks, nchunks, count, op, scale_dev, out_dev, 0.0f, 0, (unsigned long long *)nullptr);
     LAUNCHCHK("k_fold");
     return NNC_OK;
 }
@@ -525,17 +530,18 @@ extern "C" int nnc_prune_stats_f32(float *x, int64_t n, float q, int std_smooth,
         float *chunks = wsf + 16;
         const int64_t nchunks = (n + NNC_CHUNK - 1) / NNC_CHUNK;
         int rc;
-        hipLaunchKernelGGL(k_set_f32, dim3(1), dim3(1), 0, S(stream), q, scal + 1);
-        LAUNCHCHK("k_set_f32");
         if ((rc = nnc_chunk_sums_f32(x, n, 0, nullptr, chunks, stream))) return rc;
         if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_MEAN, nullptr, scal, stream))) return rc;
         if ((rc = nnc_chunk_sums_f32(x, n, 1, scal, chunks, stream))) return rc;
-        if ((rc = nnc_fold_f32(chunks, nchunks, n, NNC_FOLD_STD, scal + 1, stats_dev, stream))) return rc; // stats = {sigma, sigma * q}
+        // stats = {sigma, sigma * q}; the threshold pass's counter is zeroed on the way
+        hipLaunchKernelGGL(k_fold, dim3(1), dim3(1024), 0, S(stream), chunks, nchunks, n, (int)NNC_FOLD_STD, (const float *)nullptr, stats_dev, q, 1,
+                           reinterpret_cast<unsigned long long *>(nzeroed_dev));
+        LAUNCHCHK("k_fold");
     } else {
         hipLaunchKernelGGL(k_set_thr, dim3(1), dim3(1), 0, S(stream), q, stats_dev);
         LAUNCHCHK("k_set_thr");
+        if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
     }
-    if (nzeroed_dev) HIPCHK(hipMemsetAsync(nzeroed_dev, 0, sizeof(int64_t), S(stream)));
     MinMaxPartial *part = reinterpret_cast<MinMaxPartial *>(reinterpret_cast<unsigned char *>(ws) + ((nnc_prune_workspace_bytes(n) + 255) & ~(size_t)255));
     const bool vec = ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(mask) & 3) == 0);
     const int grid = std::min(stream_grid((n + 3) / 4, 256, 4), cu_count() * 8);
