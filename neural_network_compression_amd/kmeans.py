@@ -318,7 +318,7 @@ def fit_reference_large(x: torch.Tensor, init, max_iter: int = MAX_ITER, tol: fl
     if want_values:
         vals = torch.from_numpy(final).to(dev)[lab.to(torch.int64) if lb == 1 else (lab.to(torch.int64) & 0xFFFF)]
     model = QuantizedModel(final, lab, n_iter, n_reloc, stop)
-    counts = torch.bincount(lab.to(torch.int64) if lb == 1 else (lab.to(torch.int64) & 0xFFFF), minlength=k)
+    counts = ops.bincount(lab, k)   # (the library's index histogram, as the default path)
     model.counts_device_ = counts
     model.counts_host_ = counts.cpu().numpy().astype(np.int64)
     model.n_reloc_windowed_ = 0
@@ -653,7 +653,9 @@ class DeviceKMeans:
         dist.all_reduce(self._reloc_flag, op=dist.ReduceOp.MAX, group=self.group)   # any rank unproven -> nobody relocates
         bufs = [torch.empty_like(keys) for _ in range(dist.get_world_size(self.group))]
         dist.all_gather(bufs, keys, group=self.group)
-        merged = torch.sort(torch.cat(bufs), descending=True).values[:n_empty + 1].contiguous()
+        # (every rank's list is descending: the library's own merge, the one the RCCL path runs inside nnc_kmeans_relocate_windowed_sharded)
+        merged = torch.empty(n_empty + 1, dtype=torch.int64, device=self.dev)
+        nat.check(self.L.nnc_merge_keys(torch.cat(bufs).data_ptr(), len(bufs), n_empty + 1, merged.data_ptr(), n_empty + 1, self.stream))
         nat.check(self.L.nnc_kmeans_relocate_if_proven(ws, merged.data_ptr(), n_empty + 1, self.stream))
         nat.check(self.L.nnc_kmeans_finalize(ws, 1, self.stream))
         return True
@@ -707,8 +709,9 @@ class DeviceKMeans:
             pad[: keys.numel()] = keys
             bufs = [torch.empty_like(pad) for _ in range(world)]
             dist.all_gather(bufs, pad, group=self.group)
-            allk = torch.sort(torch.cat(bufs), descending=True).values
-            keys = allk[: min(n_empty + 1, self.n_total)].contiguous()
+            m_all = min(n_empty + 1, self.n_total)
+            keys = torch.empty(m_all, dtype=torch.int64, device=self.dev)   # (descending lists padded with -1: the library's merge; 0 where there are fewer keys)
+            nat.check(self.L.nnc_merge_keys(torch.cat(bufs).data_ptr(), world, n_empty + 1, keys.data_ptr(), m_all, self.stream))
         nat.check(self.L.nnc_kmeans_relocate(self.ws.data_ptr(), keys.data_ptr(), int(keys.numel()), self.stream))
         nat.check(self.L.nnc_kmeans_finalize(self.ws.data_ptr(), 1, self.stream))
         if flag is not None:
