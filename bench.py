@@ -15,6 +15,9 @@ per-layer Deep-Compression pass on the data already resident in HBM:
     labels + quantized values -> index histogram -> Huffman code lengths.
 
 value = (weights processed by all ranks) / (time of the slowest rank) over exactly K steps.
+prune_weigth works in place, so a step spends its input: every step (set-up, warm-up, timed) takes a batch of its own -- a copy of
+the same synthetic vector -- that is resident in HBM before the timed region starts (config.input; --input-pool-gb bounds the pool,
+beyond it the steps copy one resident vector at their head as they did until round 4).
 The JSON line also carries
   roofline     : the k-means assignment pass over the vector, k_assign<labels> (4 B read + centroid index + 4 B decoded
                  value written per weight), against the 8 TB/s HBM peak; its duration is measured with HIP events
