@@ -1532,7 +1532,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
     // by thread 0 behind the first barrier of the path taken -- every thread has its copy of it by then (the loop below needs it).
     const int qn = min(qn_raw, (int)NNC_KMAX);
     for (int r = tid; r < qn; r += NT) { ws->q_w0[r] = 0ull; ws->q_w1[r] = 0ull; ws->q_next[r] = 0; }
-    FSTAMP(34);
+    FSTAMP(44);
 #define FIN_QUEUE_RESET() do { if (tid == 0 && takes_a_pass) { ws->q_n = 0; ws->q_searched = 0; ws->help_hint = qn > 0; } } while (0)
 #define FIN_LEAVE() do { if (ONEWAVE) wave_lds_fence(); else __syncthreads(); FIN_QUEUE_RESET(); return false; } while (0)
     if (mode != FIN_INIT && mode != FIN_PACK_ONLY && st_done) FIN_LEAVE();
@@ -1571,7 +1571,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         for (int j = tid; j < k; j += NT) { sum_o[j] = 0; cnt_o[j] = 0; } // duplicates of a centre own nothing
         FIN_SYNC();
         FIN_QUEUE_RESET();
-        FSTAMP(35);
+        FSTAMP(45);
         for (int p = tid; p < ku_cur; p += NT) {
             long long s = 0;
             unsigned long long c = 0;
@@ -1588,7 +1588,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             sum_o[o] = s; cnt_o[o] = (long long)c;
         }
         FIN_SYNC();
-        FSTAMP(36);
+        FSTAMP(46);
         for (int j = tid; j < k; j += NT) {
             ws->partials[j] = sum_o[j]; ws->partials[k + j] = cnt_o[j];
             ws->partials_local[j] = sum_o[j]; ws->partials_local[k + j] = cnt_o[j];
@@ -1598,7 +1598,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
         for (int j = tid; j < k; j += NT) { sum_o[j] = ws->partials[j]; cnt_o[j] = ws->partials[k + j]; }
     }
     FIN_SYNC();
-    FSTAMP(37);
+    FSTAMP(47);
     if (!from_shards) FIN_QUEUE_RESET(); // (FIN_INIT: the first pass of a fit starts with an empty queue)
     int same_counts_now = 0;
     bool settled_event = false; // an empty-cluster event was settled in this very call (km_finalize_relocate)

@@ -47,7 +47,7 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
                       f"waves with more than 256: {int((und > 256).sum())}, more than 2048: {int((und > 2048).sum())}), most candidates {int(kb[:, 9].max()) + 1}; slowest waves: " + " ".join(desc))
         if it >= 6 and not st.paused:
             full = tr.cpu().numpy()
-            t = full[6 * 1024: 6 * 1024 + 40]
+            t = full[6 * 1024: 6 * 1024 + 48]
             if t[7] > t[0]:
                 (late if it >= 22 else acc).append((t - t[0]) * 0.01)
                 kball = full[: 16 * 300].reshape(300, 16)
@@ -71,5 +71,5 @@ for n, bits, mode in ((2_359_296, 4, "linear"), (25_000_000, 8, "density")):
               + f"; last wave's end -> finalize start {b[14]:.2f}; first wave's start -> finalize start {b[15]:.2f}; waves {b[16]:.0f}")
     if late:
         f = np.median(np.array(late), axis=0)
-        print(f"   inside shards->partials (us since start): header read + queue zeroed {f[34]:.2f}, sums zeroed + barrier {f[35]:.2f}, shards added into LDS + barrier {f[36]:.2f}, partials stored + barrier {f[37]:.2f}")
+        print(f"   inside shards->partials (us since start): header read + queue zeroed {f[44]:.2f}, sums zeroed + barrier {f[45]:.2f}, shards added into LDS + barrier {f[46]:.2f}, partials stored + barrier {f[47]:.2f}")
         print(f"n={n} K={2**bits}: k_finalize stamps, iterations 22-, median of {len(late)} (us since start): " + ", ".join(f"{nm} {f[i]:.2f}" for i, nm in order))
