@@ -311,7 +311,11 @@ int nnc_kmeans_iterate_publish(const float *x, void *ws, const nnc_kmeans_params
  * (nnc_kmeans_reloc_scratch_bytes(k, 256)) the iterations of the first batches are followed by the windowed relocation "in
  * case" -- its launches read the status themselves and do nothing without an event they can settle -- so that such events
  * cost no look-in; status_out->n_relocated counts them (included in *n_windowed_out).  status_out is read on entry (pass a
- * zeroed block for a new fit, the block of the previous call when calling again). */
+ * zeroed block for a new fit, the block of the previous call when calling again).
+ * The status of a batch of plain iterations is written two iterations before the batch ends, so that the next batch is on the
+ * stream before the device runs dry; when the call returns with done != 0, launches of iterations the host had enqueued in the
+ * meantime may still be on the stream: they read the status themselves and return at once (work enqueued behind the call on the
+ * same stream sees the finished fit, as before). */
 int nnc_kmeans_fit(const float *x_iter, void *ws, const nnc_kmeans_params *p, int32_t max_batch, int32_t sorted,
                    void *reloc_scratch_dev, size_t reloc_scratch_bytes, void *host_mapped, uint64_t *ticket_io,
                    nnc_kmeans_status *status_out, int32_t *n_windowed_out, void *stream);
