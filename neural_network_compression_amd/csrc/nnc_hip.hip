@@ -1801,7 +1801,7 @@ __device__ __forceinline__ bool km_finalize_body(KmWs *__restrict__ ws, int mode
             carry = tot;
             FIN_SYNC();
         }
-        ku = carry;
+        ku = min(carry, k); // (never more than there are centres)
     }
     FSTAMP(10);
     for (int p = tid; p < ku; p += NT) {
