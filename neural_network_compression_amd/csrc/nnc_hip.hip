@@ -1999,11 +1999,13 @@ __device__ __forceinline__ uint16_t km_cell_entry(int g, int G, int ku, const in
 // MASS: the body may settle mass empty-cluster events as well (kl_relocate_mass; nnc_kmeans_params.flags & NNC_KM_MASS_IN_PLACE).  A
 // variant of its own: the code is large, and code that runs once a launch arrives cold -- with it in the default kernel the small
 // events the finalize step settles in place went from 41-55 to 59-65 us.
+// (the kernel's body as a device function: k_finalize runs it, and so does the launch that runs the relocation chain's selection in
+// front of it, k_reloc_select_finalize)
 template <int NT, bool FUSED, bool MASS = false>
-__global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume,
-                                                                      nnc_kmeans_status *host_st, unsigned long long *host_ticket,
-                                                                      unsigned long long ticket, int lazy, const float *__restrict__ reloc_xs,
-                                                                      long long reloc_n)
+__device__ __forceinline__ void km_finalize_kernel(KmWs *__restrict__ ws, int mode, int resume,
+                                                   nnc_kmeans_status *host_st, unsigned long long *host_ticket,
+                                                   unsigned long long ticket, int lazy, const float *__restrict__ reloc_xs,
+                                                   long long reloc_n)
 {
     __shared__ int gcell[NNC_KMAX], hcell[NNC_KMAX]; // per centre: last cell it can open / first cell it can close
     __shared__ int fin_go, fin_kc[2], fin_novf; // fin_kc: {distinct centres, current table} from the body
@@ -2050,6 +2052,15 @@ __global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__re
             *reinterpret_cast<volatile unsigned long long *>(host_ticket) = ticket;
         }
     }
+}
+
+template <int NT, bool FUSED, bool MASS = false>
+__global__ __launch_bounds__(FUSED ? KM_THREADS : NT) void k_finalize(KmWs *__restrict__ ws, int mode, int resume,
+                                                                      nnc_kmeans_status *host_st, unsigned long long *host_ticket,
+                                                                      unsigned long long ticket, int lazy, const float *__restrict__ reloc_xs,
+                                                                      long long reloc_n)
+{
+    km_finalize_kernel<NT, FUSED, MASS>(ws, mode, resume, host_st, host_ticket, ticket, lazy, reloc_xs, reloc_n);
 }
 
 // A whole batch of Lloyd iterations in ONE launch, for fits with few centres on a sorted vector (k <= KM_FUSE_KMAX, rank-boundary
@@ -3262,10 +3273,10 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_dist(const float *__restri
 // One workgroup: the n_empty largest keys among the candidates (histogram cut on the distance
 // bits, refined while crowded, exact ranking of the survivors), the proof that nothing outside
 // the windows can beat them, and -- if it holds -- the relocation itself.
-__global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
-                                                             const float *__restrict__ cand_d, const KmWin *__restrict__ win,
-                                                             const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out,
-                                                             int do_relocate, const unsigned *__restrict__ hist0 = nullptr, int spec = 0)
+__device__ __forceinline__ void km_reloc_select_body(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
+                                                     const float *__restrict__ cand_d, const KmWin *__restrict__ win,
+                                                     const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out,
+                                                     int do_relocate, const unsigned *__restrict__ hist0, int spec)
 {
     if (spec) { // enqueued in case of an event: nothing to do without one; the number of empty clusters is the device's
         if (!ws->spec_go) return;
@@ -3501,6 +3512,30 @@ __global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ 
 #undef RSTAMP
 }
 
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_select(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
+                                                             const float *__restrict__ cand_d, const KmWin *__restrict__ win,
+                                                             const int *__restrict__ meta, int n_empty, long long *__restrict__ keys_out,
+                                                             int do_relocate, const unsigned *__restrict__ hist0, int spec)
+{
+    km_reloc_select_body(ws, cand_x, cand_d, win, meta, n_empty, keys_out, do_relocate, hist0, spec);
+}
+
+// The last two launches of the relocation chain enqueued "in case" as ONE (round 4): the selection, then -- the same workgroup, behind a
+// barrier -- the resumed finalize step that used to be a launch of its own (a boundary and the re-reading of what the selection has
+// just written: 5 us an event, and a launch less for every chain that finds nothing to do).  Sixteen waves either way, so only where the
+// finalize step runs with sixteen (more than 256 centres).
+__global__ __launch_bounds__(KM_THREADS) void k_reloc_select_finalize(KmWs *__restrict__ ws, const float *__restrict__ cand_x,
+                                                                      const float *__restrict__ cand_d, const KmWin *__restrict__ win,
+                                                                      const int *__restrict__ meta, long long *__restrict__ keys_out,
+                                                                      const unsigned *__restrict__ hist0, nnc_kmeans_status *host_st,
+                                                                      unsigned long long *host_ticket, unsigned long long ticket, int lazy)
+{
+    km_reloc_select_body(ws, cand_x, cand_d, win, meta, 0, keys_out, 1, hist0, 1);
+    __syncthreads();                                    // what the selection wrote (sums, counts, status) is out ...
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // ... and is read past whatever this compute unit's L1 still holds of it
+    km_finalize_kernel<KM_THREADS, false, false>(ws, FIN_FROM_PARTIALS, 2, host_st, host_ticket, ticket, lazy, nullptr, 0);
+}
+
 static std::atomic<int> g_reloc_dist_attr[NNC_MAX_DEVICES];
 // windows, candidates and their distances (two launches)
 static int km_reloc_windows_dist(const float *x_sorted, void *ws, const nnc_kmeans_params *p, int32_t window, float *cand_x,
@@ -3648,6 +3683,16 @@ static int km_launch_spec_reloc(const float *x_sorted, KmWs *w, const nnc_kmeans
     NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_dist, dim3(grid), dim3(KM_THREADS), lds, S(stream), x_sorted, (const KmWin *)win, (const int *)meta, cand_x, cand_d, (long long)cap,
                        reinterpret_cast<const KmWs *>(w), hist0, 1);
     LAUNCHCHK("k_reloc_dist");
+#ifndef KM_CHAIN_FIVE
+    if (p->k > 256 && !km_fused(p) && p->prefix_dev) { // (where km_launch_finalize would take sixteen waves and the lazy form: see k_reloc_select_finalize)
+        unsigned char *hb = reinterpret_cast<unsigned char *>(host_mapped);
+        NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_select_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, (const float *)cand_x, (const float *)cand_d, (const KmWin *)win,
+                        (const int *)meta, keys, (const unsigned *)hist0, reinterpret_cast<nnc_kmeans_status *>(hb),
+                        reinterpret_cast<unsigned long long *>(hb ? hb + sizeof(nnc_kmeans_status) : nullptr), (unsigned long long)ticket, 1 | (p->k << 8));
+        LAUNCHCHK("k_reloc_select_finalize");
+        return NNC_OK;
+    }
+#endif
     NNC_LAUNCH_PROF(NNC_PROF_RELOC, k_reloc_select, dim3(1), dim3(KM_THREADS), 0, S(stream), w, (const float *)cand_x, (const float *)cand_d, (const KmWin *)win, (const int *)meta, 0, keys, 1, (const unsigned *)hist0, 1);
     LAUNCHCHK("k_reloc_select");
     return km_launch_finalize(w, p, FIN_FROM_PARTIALS, 2, stream, host_mapped, ticket);
