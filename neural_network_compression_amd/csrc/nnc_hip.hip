@@ -2256,8 +2256,8 @@ int km_check(void *ws, const nnc_kmeans_params *p, const char *who)
     return NNC_OK;
 }
 
-__global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_params p, int glog2, int rlog2, float inv,
-                                                        const float *__restrict__ centers_init)
+__device__ __forceinline__ void km_init_body(KmWs *ws, const nnc_kmeans_params &p, int glog2, int rlog2, float inv,
+                                             const float *__restrict__ centers_init)
 {
     const int tid = threadIdx.x;
     if (tid == 0) {
@@ -2281,6 +2281,23 @@ __global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_par
     if (tid < 24) ws->kl_trace[tid] = 0ull;
 }
 
+__global__ __launch_bounds__(KM_THREADS) void k_km_init(KmWs *ws, nnc_kmeans_params p, int glog2, int rlog2, float inv,
+                                                        const float *__restrict__ centers_init)
+{
+    km_init_body(ws, p, glog2, rlog2, inv, centers_init);
+}
+
+// ... and the table of the initial centres in the same launch, where the finalize step runs with the same sixteen waves and leaves
+// the cell table alone (more than 256 centres on a sorted vector with prefix sums): one launch boundary less at the head of a fit
+__global__ __launch_bounds__(KM_THREADS) void k_km_init_finalize(KmWs *ws, nnc_kmeans_params p, int glog2, int rlog2, float inv,
+                                                                 const float *__restrict__ centers_init)
+{
+    km_init_body(ws, p, glog2, rlog2, inv, centers_init);
+    __syncthreads();                                    // the workspace is written ...
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // ... and read past this compute unit's L1
+    km_finalize_kernel<KM_THREADS, false, false>(ws, FIN_INIT, 0, nullptr, nullptr, 0ull, 1 | (p.k << 8), nullptr, 0);
+}
+
 extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_params *p, const float *centers_init_dev,
                                void *stream)
 {
@@ -2300,6 +2317,13 @@ extern "C" int nnc_kmeans_init(void *ws, size_t ws_bytes, const nnc_kmeans_param
     if (range > 0.0) inv = (float)(((double)(1 << glog2)) / range * (1.0 - 1.0 / 1048576.0));
     if (!std::isfinite(inv)) inv = 0.0f;
     KmWs *w = reinterpret_cast<KmWs *>(ws);
+#ifndef KM_INIT_TWO
+    if (p->k > 256 && !km_fused(p) && p->prefix_dev) {
+        hipLaunchKernelGGL(k_km_init_finalize, dim3(1), dim3(KM_THREADS), 0, S(stream), w, *p, glog2, rlog2, inv, centers_init_dev);
+        LAUNCHCHK("k_km_init_finalize");
+        return NNC_OK;
+    }
+#endif
     hipLaunchKernelGGL(k_km_init, dim3(1), dim3(KM_THREADS), 0, S(stream), w, *p, glog2, rlog2, inv, centers_init_dev);
     LAUNCHCHK("k_km_init");
     return km_launch_finalize(w, p, FIN_INIT, 0, stream);
