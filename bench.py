@@ -208,6 +208,42 @@ def _init_ranks(args):
     return torch, rank, world, dev, group, comm, comm_note
 
 
+def _comm_preflight(torch, comm, rank, world, dev):
+    """The library's communicator is believed only after it has added up what torch.distributed adds up: rank r contributes r + 1 in
+    every word of a block the size of an iteration's exchange (2 K int64).  Returns (comm or None, note)."""
+    if comm is None:
+        return None, None
+    try:
+        probe = torch.full((2 * 1040,), rank + 1, dtype=torch.int64, device=dev)
+        comm.allreduce_(probe)
+        torch.cuda.synchronize(dev)
+        if not bool((probe == world * (world + 1) // 2).all().item()):
+            raise RuntimeError("the library's all-reduce returned a wrong sum")
+        return comm, None
+    except Exception as e:  # noqa: BLE001 - reported in the JSON line and on stderr
+        note = f"pre-flight all-reduce: {type(e).__name__}: {e}"
+        print(f"[bench] rank {rank}: {note}; falling back to torch.distributed", file=sys.stderr)
+        try:
+            comm.close()
+        except Exception:  # noqa: BLE001
+            pass
+        return None, note
+
+
+def _comm_checked(torch, dist, group, comm, comm_note, rank, world, dev):
+    """Every rank has the communicator (or none has): try it, then agree on the verdict -- one rank's doubt drops it everywhere."""
+    if comm is None:
+        return None, comm_note
+    comm, note = _comm_preflight(torch, comm, rank, world, dev)
+    ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 0 and comm is not None:
+        comm.close()
+        comm = None
+        note = note or "another rank's pre-flight all-reduce failed"
+    return comm, (comm_note or note)
+
+
 def cpu_baseline_config4(args, layers):
     """The reference's CPU path on a stated subset of configs[4]: the ten tensors of transformer block 0 (7.1 M of the 124.4 M
     weights: the four matrix shapes and the six 1-D tensors every block repeats), same seeds as the GPU run."""
@@ -262,6 +298,7 @@ def main_config4(args):
         if int(ok.item()) == 0 and comm is not None:
             comm.close()
             comm = None
+        comm, comm_note = _comm_checked(torch, dist, group, comm, comm_note, rank, world, dev)
     held = []
     for i, (name, shape) in enumerate(layers):
         if owner[i] == rank:
@@ -416,6 +453,7 @@ def main():
             comm.close()
             comm = None
             comm_note = comm_note or "another rank could not create it"
+        comm, comm_note = _comm_checked(torch, dist, group, comm, comm_note, rank, world, dev)
     w_host = synth.weights((hi - lo,), SEED, start=lo)
     w0 = torch.from_numpy(w_host).to(dev)
 
